@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_vectors.json by running the UNMODIFIED reference.
+
+Dev-container only: imports /root/reference/afskmodem.py in place (with a stub
+``pyaudio`` injected, the only missing dependency; it does audio-device I/O and
+is off the hot path) and records input parameters + the reference's outputs.
+Nothing of the reference's source is copied: the fixture holds data only
+(payloads, parameters, integers, bit/byte strings, SHA-256 of sample arrays).
+
+Noisy inputs use the build-owned deterministic integer noise generator
+(oracle ``add_noise``; same arithmetic as the HIP ``afsk_add_noise_batch``), so
+tests can regenerate every input bit-exactly from (payload, baud, seed, scale)
+and check its SHA-256 against the one recorded here.
+
+Run:  python tests/golden/make_golden.py      (needs /root/reference)
+"""
+from __future__ import annotations
+
+import contextlib
+import hashlib
+import io
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import afsk_oracle as O  # noqa: E402  (noise generator + framing helpers)
+
+
+def import_reference():
+    stub = types.ModuleType("pyaudio")
+    stub.paInt16 = 8
+
+    class _Stream:
+        def start_stream(self): pass
+        def stop_stream(self): pass
+        def close(self): pass
+        def read(self, n): return b"\x00\x00" * n
+        def write(self, *a, **k): pass
+
+    class _PA:
+        def open(self, **kw): return _Stream()
+
+    stub.Stream = _Stream
+    stub.PyAudio = _PA
+    sys.modules["pyaudio"] = stub
+    sys.path.insert(0, "/root/reference")
+    import afskmodem as ref  # type: ignore
+    return ref
+
+
+ref = import_reference()
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.asarray(a, dtype="<i2").tobytes()).hexdigest()
+
+
+def snr_to_scale_q24(snr_db: float) -> int:
+    """sigma = 32767.5 / 10^(snr/20); generator std = sqrt(16*(65536^2-1)/12)."""
+    sigma = 32767.5 / (10.0 ** (snr_db / 20.0))
+    gen_std = (16.0 * (65536.0 ** 2 - 1.0) / 12.0) ** 0.5
+    return int(round(sigma / gen_std * (1 << 24)))
+
+
+def ref_decode(frames: list[int], baud: int, amp_end: int = 14000):
+    """Run the reference hot path + ECC tail on a frame list; capture debug lines."""
+    ref.LOG_LEVEL = 0
+    r = ref.Receiver(baud, 18000, amp_end)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bits = r._Receiver__decodeBits(list(frames))
+    log = buf.getvalue()
+    m_ci = re.search(r"Recovered clock\. \(frame (\d+)\)", log)
+    m_tf = re.search(r"Training sequence terminated on frame (\d+)", log)
+    ci = int(m_ci.group(1)) if m_ci else -1
+    tf = int(m_tf.group(1)) if m_tf else -1
+    if bits == "":
+        data = b""
+    else:
+        data = r._Receiver__bitsToBytes(ref.ECC.decode(bits))
+    ref.LOG_LEVEL = 5
+    return {"clock_idx": ci, "term_frame": tf, "nbits": len(bits), "bits": bits,
+            "bytes_hex": data.hex(), "nbytes": len(data)}
+
+
+def main():
+    ref.LOG_LEVEL = 5
+    G: dict = {"generator": "tests/golden/make_golden.py",
+               "reference": "lavajuno/afskmodem afskmodem.py (484 lines) at /root/reference"}
+
+    # ---- 1. Waveforms templates + baud validity table (ref:68-91)
+    tpl = {}
+    for baud in (300, 600, 1200, 2400):
+        tpl[str(baud)] = {
+            "space": ref.Waveforms.getSpaceTone(baud),
+            "mark": ref.Waveforms.getMarkTone(baud),
+            "training": ref.Waveforms.getTrainingCycle(baud),
+        }
+    G["templates"] = tpl
+
+    validity = {}
+    bauds = [100, 150, 200, 300, 400, 480, 500, 600, 750, 800, 960, 1000, 1200, 1500, 1600,
+             2000, 2400, 3000, 3200, 4000, 4800, 6000, 8000, 9600, 12000, 16000, 24000, 20, 7, 1100]
+    import tempfile
+    tmpdir = tempfile.mkdtemp()
+    for baud in bauds:
+        entry = {}
+        try:
+            t = ref.Transmitter(baud)
+            r = ref.Receiver(baud)
+            entry["construct"] = "ok"
+        except Exception as e:  # noqa: BLE001
+            entry["construct"] = f"{type(e).__name__}: {e}"
+            validity[str(baud)] = entry
+            continue
+        try:
+            fn = os.path.join(tmpdir, f"v{baud}.wav")
+            t.save(b"Hi!", fn)
+            got = r.load(fn, False)
+            entry["roundtrip"] = "ok" if got == b"Hi!" else f"bytes:{got.hex()}"
+        except Exception as e:  # noqa: BLE001
+            entry["roundtrip"] = f"{type(e).__name__}: {e}"
+        validity[str(baud)] = entry
+    G["baud_validity"] = validity
+
+    # ---- 2. ECC (ref:114-175)
+    ecc = {"codewords": {}, "decode_table": {}, "short": {}}
+    for v in range(16):
+        b = format(v, "04b")
+        ecc["codewords"][b] = ref.ECC.encode(b)
+    for v in range(128):
+        b = format(v, "07b")
+        ecc["decode_table"][b] = ref.ECC.decode(b)
+    for s in ("", "1", "101", "101011", "1010110", "101010", "10101011", "1111111000000"):
+        ecc["short"][s] = {"encode": ref.ECC.encode(s), "decode": ref.ECC.decode(s)}
+    G["ecc"] = ecc
+
+    # ---- 3. Transmitter frames + wav quirk (ref:452-469, 239-244)
+    rng = np.random.default_rng(20240415)
+    payloads = {
+        "hello": b"Hello World!",
+        "utf8": "Héellóo World!".encode("utf-8"),
+        "empty": b"",
+        "A": b"A",
+        "rand8": rng.integers(0, 256, 8, dtype=np.uint8).tobytes(),
+        "rand34": rng.integers(0, 256, 34, dtype=np.uint8).tobytes(),
+        "rand68": rng.integers(0, 256, 68, dtype=np.uint8).tobytes(),
+        "fffefd": b"\xff\xfe\xfd",
+    }
+    frames_cases = []
+    for name, data in payloads.items():
+        for baud in (300, 1200, 2400):
+            for tt in (0.5, 0.1, 0.0):
+                t = ref.Transmitter(baud, tt)
+                fr = t._Transmitter__getFrames(data)
+                wav = ref.SoundOutput._SoundOutput__convertFrames(fr)
+                wav_i16 = np.frombuffer(wav, dtype="<i2")
+                ndiff = int(np.count_nonzero(wav_i16 != np.asarray(fr[:len(wav_i16)])))
+                frames_cases.append({
+                    "payload": name, "payload_hex": data.hex(), "baud": baud,
+                    "training_time": tt, "n_frames": len(fr), "frames_sha256": sha(fr),
+                    "n_wav": len(wav_i16), "wav_sha256": sha(wav_i16), "wav_vs_ideal_diff": ndiff,
+                })
+    G["frames"] = frames_cases
+
+    # ---- 4. primitives on random windows with edge values (ref:94-107, 287-296)
+    prim = []
+    edge = [-32768, -32767, -513, -512, -511, -1, 0, 1, 511, 512, 513, 32766, 32767]
+    for n in (20, 40, 80, 160):
+        for k in range(4):
+            a = rng.integers(-32768, 32768, n).tolist()
+            b = rng.integers(-32768, 32768, n).tolist()
+            for j, e in enumerate(edge):
+                if (j * 3 + k) % n < n:
+                    a[(j * 3 + k) % n] = e
+            if k == 3:
+                a = [-32768] * n
+                b = [32767] * n
+            prim.append({"a": a, "b": b, "diff": ref.Waveforms.getDiff(a, b),
+                         "amp_a": ref.Waveforms.getAmplitude(a),
+                         "amplified_a": ref.Receiver(1200)._Receiver__amplify(a)})
+    G["primitives"] = prim
+
+    # ---- 5. decode cases (ref:322-381, 420-427)
+    cases = []
+
+    def add_case(tag, frames, baud, amp_end=14000, gen=None):
+        out = ref_decode(frames, baud, amp_end)
+        rec = {"tag": tag, "baud": baud, "amp_end": amp_end, "n_samples": len(frames),
+               "input_sha256": sha(frames), "gen": gen}
+        rec.update(out)
+        bits = rec.pop("bits")
+        rec["bits_sha256"] = hashlib.sha256(bits.encode()).hexdigest()
+        if len(bits) <= 256:
+            rec["bits"] = bits
+        cases.append(rec)
+        return rec
+
+    def wav_frames(data: bytes, baud: int, tt: float = 0.5, total: int | None = None):
+        t = ref.Transmitter(baud, tt)
+        fr = t._Transmitter__getFrames(data)
+        wav = np.frombuffer(ref.SoundOutput._SoundOutput__convertFrames(fr), dtype="<i2")
+        wav = wav.astype(np.int16)
+        if total is not None:
+            assert len(wav) <= total, (len(wav), total)
+            wav = np.concatenate([wav, np.zeros(total - len(wav), np.int16)])
+        return wav
+
+    # clean round trips through the wav quirk, native length
+    for name in ("hello", "utf8", "A", "fffefd", "empty"):
+        for baud in (300, 1200, 2400):
+            w = wav_frames(payloads[name], baud)
+            add_case(f"clean/{name}/{baud}", w.tolist(), baud,
+                     gen={"kind": "wav", "payload_hex": payloads[name].hex(), "baud": baud,
+                          "training_time": 0.5, "total": None})
+    # 1 s streams: 8 / 34 / 68 byte payloads, zero padded to 48000
+    for name, baud in (("rand8", 300), ("rand34", 1200), ("rand68", 2400)):
+        w = wav_frames(payloads[name], baud, 0.5, 48000)
+        add_case(f"clean1s/{name}/{baud}", w.tolist(), baud,
+                 gen={"kind": "wav", "payload_hex": payloads[name].hex(), "baud": baud,
+                      "training_time": 0.5, "total": 48000})
+    # short training
+    for tt in (0.1, 0.0):
+        w = wav_frames(payloads["hello"], 1200, tt, 24000)
+        add_case(f"training{tt}/hello/1200", w.tolist(), 1200,
+                 gen={"kind": "wav", "payload_hex": payloads["hello"].hex(), "baud": 1200,
+                      "training_time": tt, "total": 24000})
+    # degenerate inputs
+    add_case("zeros48000", [0] * 48000, 1200, gen={"kind": "zeros", "total": 48000})
+    add_case("too_short4000", wav_frames(b"A", 1200).tolist()[:4000], 1200,
+             gen={"kind": "wav_trunc", "payload_hex": b"A".hex(), "baud": 1200,
+                  "training_time": 0.5, "trunc": 4000})
+    add_case("exact4096", wav_frames(b"A", 1200).tolist()[:4096], 1200,
+             gen={"kind": "wav_trunc", "payload_hex": b"A".hex(), "baud": 1200,
+                  "training_time": 0.5, "trunc": 4096})
+    tr_only = ref.Waveforms.getTrainingCycle(1200) * 300
+    add_case("training_only", tr_only, 1200, gen={"kind": "training_only", "baud": 1200,
+                                                  "cycles": 300})
+    # no tail silence: the symbol that ends exactly at the buffer end is dropped (ref:362,372)
+    t = ref.Transmitter(1200, 0.1)
+    fr = t._Transmitter__getFrames(b"AB")
+    fr = fr[:-4800]
+    add_case("no_tail", fr, 1200, gen={"kind": "frames_trunc_tail", "payload_hex": b"AB".hex(),
+                                        "baud": 1200, "training_time": 0.1, "extra": 0})
+    add_case("no_tail_plus1", fr + [0], 1200,
+             gen={"kind": "frames_trunc_tail", "payload_hex": b"AB".hex(), "baud": 1200,
+                  "training_time": 0.1, "extra": 1})
+    # different squelch threshold
+    w = wav_frames(payloads["hello"], 1200)
+    add_case("amp_end_40000", w.tolist(), 1200, amp_end=40000,
+             gen={"kind": "wav", "payload_hex": payloads["hello"].hex(), "baud": 1200,
+                  "training_time": 0.5, "total": None})
+    add_case("amp_end_0", w.tolist(), 1200, amp_end=0,
+             gen={"kind": "wav", "payload_hex": payloads["hello"].hex(), "baud": 1200,
+                  "training_time": 0.5, "total": None})
+    # a leading offset (clock index != 0): prepend silence / junk
+    for lead in (1, 7, 33, 250, 1001):
+        w = np.concatenate([np.zeros(lead, np.int16), wav_frames(payloads["rand34"], 1200)])
+        add_case(f"lead{lead}", w.tolist(), 1200,
+                 gen={"kind": "wav_lead", "payload_hex": payloads["rand34"].hex(), "baud": 1200,
+                      "training_time": 0.5, "lead": lead})
+    # noisy sweep (config 4 shape): 1 s, 1200 baud, 34 B; plus a few at 300 / 2400
+    for snr in (30, 20, 15, 10, 7, 5, 3, 0):
+        for seed in range(4):
+            data = rng.integers(0, 256, 34, dtype=np.uint8).tobytes()
+            w = wav_frames(data, 1200, 0.5, 48000)
+            q = snr_to_scale_q24(snr)
+            noisy = O.add_noise(w, seed=1000 + seed, stream_idx=snr, scale_q24=q)
+            add_case(f"noise/1200/snr{snr}/seed{seed}", noisy.tolist(), 1200,
+                     gen={"kind": "wav_noise", "payload_hex": data.hex(), "baud": 1200,
+                          "training_time": 0.5, "total": 48000, "seed": 1000 + seed,
+                          "stream_idx": snr, "scale_q24": q, "snr_db": snr})
+    for baud, nb in ((300, 8), (2400, 68)):
+        for snr in (20, 7, 3):
+            data = rng.integers(0, 256, nb, dtype=np.uint8).tobytes()
+            w = wav_frames(data, baud, 0.5, 48000)
+            q = snr_to_scale_q24(snr)
+            noisy = O.add_noise(w, seed=77, stream_idx=baud + snr, scale_q24=q)
+            add_case(f"noise/{baud}/snr{snr}", noisy.tolist(), baud,
+                     gen={"kind": "wav_noise", "payload_hex": data.hex(), "baud": baud,
+                          "training_time": 0.5, "total": 48000, "seed": 77,
+                          "stream_idx": baud + snr, "scale_q24": q, "snr_db": snr})
+    # other valid bauds, clean + mild noise
+    for baud in (100, 600, 4000, 6000):
+        data = rng.integers(0, 256, 5, dtype=np.uint8).tobytes()
+        w = wav_frames(data, baud, 0.5)
+        add_case(f"clean/rand5/{baud}", w.tolist(), baud,
+                 gen={"kind": "wav", "payload_hex": data.hex(), "baud": baud,
+                      "training_time": 0.5, "total": None})
+    G["decode_cases"] = cases
+
+    # ---- 6. README assertion (README.md:47-66)
+    fn = os.path.join(tmpdir, "afsk.wav")
+    ref.Transmitter(1200).save("Héellóo World!", fn)
+    G["readme_roundtrip"] = ref.Receiver(1200).load(fn, True)
+    with open(fn, "rb") as f:
+        G["readme_wav_file_sha256"] = hashlib.sha256(f.read()).hexdigest()
+
+    out = os.path.join(HERE, "reference_vectors.json")
+    with open(out, "w") as f:
+        json.dump(G, f, separators=(",", ":"))
+    print("wrote", out, os.path.getsize(out), "bytes;", len(cases), "decode cases")
+
+
+if __name__ == "__main__":
+    main()

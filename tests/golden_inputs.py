@@ -1,0 +1,49 @@
+"""Rebuild the sample arrays of tests/golden/reference_vectors.json from their
+recorded generation parameters (test helper; uses the CPU oracle's framing and
+noise generator, both themselves pinned by SHA-256 values in the fixture)."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from oracle import afsk_oracle as O
+
+
+def sha_i16(a) -> str:
+    return hashlib.sha256(np.asarray(a, dtype="<i2").tobytes()).hexdigest()
+
+
+def _wav(payload_hex: str, baud: int, training_time: float, total=None) -> np.ndarray:
+    w = O.wav_convert(O.get_frames(bytes.fromhex(payload_hex), baud, training_time))
+    if total is not None:
+        w = np.concatenate([w, np.zeros(total - len(w), np.int16)])
+    return w
+
+
+def build_input(case: dict) -> np.ndarray:
+    g = case["gen"]
+    kind = g["kind"]
+    if kind == "wav":
+        x = _wav(g["payload_hex"], g["baud"], g["training_time"], g.get("total"))
+    elif kind == "zeros":
+        x = np.zeros(g["total"], np.int16)
+    elif kind == "wav_trunc":
+        x = _wav(g["payload_hex"], g["baud"], g["training_time"])[: g["trunc"]]
+    elif kind == "training_only":
+        x = np.tile(O.training_cycle(g["baud"]), g["cycles"])
+    elif kind == "frames_trunc_tail":
+        fr = O.get_frames(bytes.fromhex(g["payload_hex"]), g["baud"], g["training_time"])[:-4800]
+        x = np.concatenate([fr, np.zeros(g["extra"], np.int16)])
+    elif kind == "wav_lead":
+        x = np.concatenate([np.zeros(g["lead"], np.int16),
+                            _wav(g["payload_hex"], g["baud"], g["training_time"])])
+    elif kind == "wav_noise":
+        x = _wav(g["payload_hex"], g["baud"], g["training_time"], g["total"])
+        x = O.add_noise(x, g["seed"], g["stream_idx"], g["scale_q24"])
+    else:
+        raise ValueError(kind)
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    assert len(x) == case["n_samples"], (case["tag"], len(x), case["n_samples"])
+    assert sha_i16(x) == case["input_sha256"], case["tag"]
+    return x

@@ -1,0 +1,110 @@
+"""Pin the CPU oracle (oracle/afsk_oracle.c) to vectors produced by the imported
+reference (tests/golden/make_golden.py).  CPU-only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import afsk_oracle as O
+from tests.golden_inputs import build_input, sha_i16
+
+
+def test_templates(golden):
+    for baud, t in golden["templates"].items():
+        b = int(baud)
+        assert O.space_tone(b).tolist() == t["space"]
+        assert O.mark_tone(b).tolist() == t["mark"]
+        assert O.training_cycle(b).tolist() == t["training"]
+
+
+def test_baud_validity(golden):
+    """ref:69-70 / :102-103 / :332 -- same accept/raise behaviour per baud."""
+    for baud, e in golden["baud_validity"].items():
+        b = int(baud)
+        if e["construct"] != "ok":
+            with pytest.raises(O.OracleError, match="Invalid baud rate"):
+                O.space_tone(b), O.mark_tone(b)
+            continue
+        O.space_tone(b), O.mark_tone(b), O.training_cycle(b)
+        frames = O.wav_convert(O.get_frames(b"Hi!", b))
+        rt = e["roundtrip"]
+        if rt == "ok":
+            assert O.load_frames(frames, b) == b"Hi!"
+        elif rt.startswith("bytes:"):
+            assert O.load_frames(frames, b) == bytes.fromhex(rt[6:])
+        elif "different lengths" in rt:
+            with pytest.raises(O.OracleError, match="different lengths"):
+                O.load_frames(frames, b)
+        elif "IndexError" in rt:
+            with pytest.raises(O.OracleError, match="list index out of range"):
+                O.load_frames(frames, b)
+        else:
+            raise AssertionError(rt)
+
+
+def test_ecc(golden):
+    e = golden["ecc"]
+    for k, v in e["codewords"].items():
+        assert O.ecc_encode(k) == v
+    for k, v in e["decode_table"].items():
+        assert O.ecc_decode(k) == v
+    for k, v in e["short"].items():
+        assert O.ecc_encode(k) == v["encode"]
+        assert O.ecc_decode(k) == v["decode"]
+
+
+def test_frames_and_wav_quirk(golden):
+    for c in golden["frames"]:
+        fr = O.get_frames(bytes.fromhex(c["payload_hex"]), c["baud"], c["training_time"])
+        assert len(fr) == c["n_frames"]
+        assert sha_i16(fr) == c["frames_sha256"]
+        wav = O.wav_convert(fr)
+        assert len(wav) == c["n_wav"]
+        assert sha_i16(wav) == c["wav_sha256"]
+        assert int(np.count_nonzero(wav != fr[: len(wav)])) == c["wav_vs_ideal_diff"]
+
+
+def test_primitives(golden):
+    for p in golden["primitives"]:
+        assert O.get_diff(p["a"], p["b"]) == p["diff"]
+        assert O.get_amplitude(p["a"]) == p["amp_a"]
+        assert O.amplify(p["a"]).tolist() == p["amplified_a"]
+
+
+def test_decode_cases(golden):
+    for c in golden["decode_cases"]:
+        x = build_input(c)
+        bits, ci, tf = O.decode_bits(x, c["baud"], c["amp_end"])
+        assert ci == c["clock_idx"], c["tag"]
+        assert tf == c["term_frame"], c["tag"]
+        assert len(bits) == c["nbits"], c["tag"]
+        assert hashlib.sha256(bits.encode()).hexdigest() == c["bits_sha256"], c["tag"]
+        data = O.load_frames(x, c["baud"], c["amp_end"])
+        assert data.hex() == c["bytes_hex"], c["tag"]
+
+
+def test_demod_batch_matches_cases(golden):
+    """The batched entry (the C-ABI's host twin) against the same cases, ragged batch."""
+    cases = [c for c in golden["decode_cases"]]
+    xs = [build_input(c) for c in cases]
+    off = np.cumsum([0] + [len(x) for x in xs[:-1]]).astype(np.int64)
+    ln = np.array([len(x) for x in xs], np.int32)
+    bf = np.array([48000 // c["baud"] for c in cases], np.int32)
+    flat = np.concatenate(xs)
+    for amp_end in sorted({c["amp_end"] for c in cases}):
+        out = O.demod_batch(flat, off, ln, bf, amp_end, out_stride=160, n_threads=2)
+        for i, c in enumerate(cases):
+            if c["amp_end"] != amp_end:
+                continue
+            assert out["clock_idx"][i] == c["clock_idx"], c["tag"]
+            assert out["term_frame"][i] == c["term_frame"], c["tag"]
+            assert out["nbits"][i] == c["nbits"], c["tag"]
+            assert out["nbytes"][i] == c["nbytes"], c["tag"]
+            assert out["bytes"][i, : c["nbytes"]].tobytes().hex() == c["bytes_hex"], c["tag"]
+            want = 1 if c["clock_idx"] == -1 else (2 if c["nbits"] == 0 else 0)
+            assert out["status"][i] == want, c["tag"]
+
+
+def test_readme_roundtrip(golden):
+    w = O.wav_convert(O.get_frames("Héellóo World!".encode(), 1200))
+    assert O.load_frames(w, 1200).decode("utf-8") == golden["readme_roundtrip"]
