@@ -1,0 +1,215 @@
+"""Batched, device-resident front end of the HIP demodulator.
+
+``demod_batch`` is the benchmarked entry: all inputs and outputs are torch
+tensors already resident in HBM (torch is used for device memory and streams
+only), and the call is one asynchronous kernel launch through the C-ABI
+``afsk_demod_batch``.  Per-stream semantics are those of the reference's
+``Receiver.__decodeBits`` + ``ECC.decode`` + ``__bitsToBytes``
+(afskmodem.py:354-381, 154-163, 393-399).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native
+
+SAMPLE_RATE = _native.SAMPLE_RATE
+SYNC_WINDOW = _native.SYNC_WINDOW
+
+
+def validate_bit_frames(bit_frames) -> None:
+    """Host-side twin of the reference's baud errors (ref:69-70, 102-103, 332)."""
+    bf = np.atleast_1d(np.asarray(bit_frames))
+    if np.any(bf <= 0) or np.any(SAMPLE_RATE % np.maximum(bf, 1) != 0) or np.any(bf % 2 != 0):
+        raise Exception("Invalid baud rate.")   # 48000 % baud or 48000 % (2*baud) != 0
+    if np.any(2 * bf >= SYNC_WINDOW):
+        raise IndexError("list index out of range")
+    if np.any(bf % 4 != 0):
+        raise Exception("Comparing two waveforms of different lengths.")
+
+
+def out_stride_for(max_len: int, min_bit_frames: int) -> int:
+    """Bytes per output row that can never truncate: one byte per 14 symbols."""
+    return int(max_len // (14 * max(min_bit_frames, 4)) + 2 + 3) & ~3
+
+
+# ----------------------------------------------------------------- host arrays
+
+
+@dataclass
+class HostDemodResult:
+    bytes: np.ndarray        # uint8 [n, stride]
+    nbytes: np.ndarray       # int32 [n]
+    nbits: np.ndarray
+    clock_idx: np.ndarray
+    term_frame: np.ndarray
+    status: np.ndarray
+
+    def payloads(self) -> list[bytes]:
+        stride = self.bytes.shape[1]
+        return [self.bytes[i, : min(int(n), stride)].tobytes() for i, n in enumerate(self.nbytes)]
+
+
+def demod_host_arrays(arrays, bit_frames, amp_end_threshold: int = 14000) -> HostDemodResult:
+    """Demodulate a list of host int16 arrays (ragged) through ``afsk_demod_batch_host``."""
+    n = len(arrays)
+    lens = np.array([len(a) for a in arrays], dtype=np.int32)
+    bf = np.broadcast_to(np.asarray(bit_frames, dtype=np.int32), (n,)).copy()
+    if n:
+        validate_bit_frames(bf)
+    offs = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    flat = (np.concatenate([np.ascontiguousarray(a, dtype=np.int16) for a in arrays])
+            if n else np.zeros(0, np.int16))
+    if flat.size == 0:
+        flat = np.zeros(1, np.int16)
+        total = 0
+    else:
+        total = flat.size
+    stride = out_stride_for(int(lens.max()) if n else 0, int(bf.min()) if n else 4)
+    res = HostDemodResult(np.zeros((n, stride), np.uint8), *(np.zeros(n, np.int32) for _ in range(5)))
+    if n == 0:
+        return res
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+    _native.check(_native.lib().afsk_demod_batch_host(
+        p(flat, C.c_int16), total, p(offs, C.c_int64), p(lens, C.c_int32), p(bf, C.c_int32),
+        int(amp_end_threshold), n, p(res.bytes, C.c_uint8), stride, p(res.nbytes, C.c_int32),
+        p(res.nbits, C.c_int32), p(res.clock_idx, C.c_int32), p(res.term_frame, C.c_int32),
+        p(res.status, C.c_int32)))
+    return res
+
+
+# --------------------------------------------------------------- device tensors
+
+
+def _torch():
+    import torch
+    return torch
+
+
+@dataclass
+class DemodResult:
+    """Device-resident outputs of one ``demod_batch`` launch (all torch tensors)."""
+    bytes: "object"          # uint8 [n, stride]
+    nbytes: "object"         # int32 [n]
+    nbits: "object"
+    clock_idx: "object"
+    term_frame: "object"
+    status: "object"
+
+    def cpu(self) -> HostDemodResult:
+        return HostDemodResult(*(t.cpu().numpy() for t in
+                                 (self.bytes, self.nbytes, self.nbits, self.clock_idx,
+                                  self.term_frame, self.status)))
+
+    def payloads(self) -> list[bytes]:
+        return self.cpu().payloads()
+
+
+def alloc_result(n_streams: int, out_stride: int, device) -> DemodResult:
+    torch = _torch()
+    i32 = lambda: torch.empty(n_streams, dtype=torch.int32, device=device)  # noqa: E731
+    return DemodResult(torch.zeros((n_streams, out_stride), dtype=torch.uint8, device=device),
+                       i32(), i32(), i32(), i32(), i32())
+
+
+def uniform_layout(n_streams: int, stream_len: int, device):
+    """Offsets/lengths of n equally long, back-to-back streams."""
+    torch = _torch()
+    off = torch.arange(n_streams, dtype=torch.int64, device=device) * int(stream_len)
+    ln = torch.full((n_streams,), int(stream_len), dtype=torch.int32, device=device)
+    return off, ln
+
+
+def _as_device_i32(x, n, device):
+    torch = _torch()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.int32).contiguous()
+    arr = np.broadcast_to(np.asarray(x, dtype=np.int32), (n,)).copy()
+    return torch.from_numpy(arr).to(device)
+
+
+def _stream_ptr(stream):
+    torch = _torch()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshold: int = 14000,
+                out: DemodResult | None = None, out_stride: int | None = None, stream=None,
+                validate: bool = True) -> DemodResult:
+    """One kernel launch over n independent streams resident in HBM.
+
+    samples        int16 CUDA tensor holding every stream
+    stream_offset  int64 CUDA tensor [n], first sample of each stream
+    stream_len     int32 CUDA tensor [n]
+    bit_frames     int, sequence or tensor [n]: 48000 / baud per stream
+    out            preallocated DemodResult to reuse (no allocation in the call)
+    Asynchronous on ``stream`` (default: torch's current stream).
+    """
+    torch = _torch()
+    _native.require_device()
+    if not (isinstance(samples, torch.Tensor) and samples.is_cuda and samples.dtype == torch.int16):
+        raise TypeError("samples must be an int16 CUDA tensor (HBM resident)")
+    if not samples.is_contiguous():
+        raise ValueError("samples must be contiguous")
+    n = int(stream_offset.numel())
+    dev = samples.device
+    if validate and not isinstance(bit_frames, torch.Tensor):
+        validate_bit_frames(bit_frames)
+    bf = _as_device_i32(bit_frames, n, dev)
+    if stream_offset.dtype != torch.int64 or stream_len.dtype != torch.int32:
+        raise TypeError("stream_offset must be int64 and stream_len int32")
+    if not (stream_offset.is_cuda and stream_len.is_cuda):
+        raise TypeError("stream_offset / stream_len must be CUDA tensors")
+    if out is None:
+        if out_stride is None:
+            raise ValueError("pass out= or out_stride=")
+        out = alloc_result(n, int(out_stride), dev)
+    stride = int(out.bytes.shape[1])
+    _native.check(_native.lib().afsk_demod_batch(
+        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
+        int(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+        out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+        out.status.data_ptr(), _stream_ptr(stream)))
+    # keep the bit_frames tensor alive until the launch has been enqueued on the stream
+    out._bf_keepalive = bf  # type: ignore[attr-defined]
+    return out
+
+
+def modulate_batch(payload, payload_len, bit_frames, ts_cycles, stream_offset, stream_len,
+                   max_stream_len: int, samples, wav_quirk: bool = True, stream=None) -> None:
+    """On-device Transmitter.__getFrames + .wav quirk (ref:452-469, 239-244) into ``samples``.
+
+    payload uint8 CUDA [n, stride]; payload_len / bit_frames / ts_cycles int32 CUDA [n].
+    """
+    torch = _torch()
+    _native.require_device()
+    n = int(stream_offset.numel())
+    for t, dt in ((payload, torch.uint8), (payload_len, torch.int32), (bit_frames, torch.int32),
+                  (ts_cycles, torch.int32), (stream_offset, torch.int64),
+                  (stream_len, torch.int32), (samples, torch.int16)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dt and t.is_contiguous()):
+            raise TypeError("modulate_batch wants contiguous CUDA tensors of the documented dtypes")
+    _native.check(_native.lib().afsk_modulate_batch(
+        payload.data_ptr(), int(payload.shape[1]), payload_len.data_ptr(), bit_frames.data_ptr(),
+        ts_cycles.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
+        int(max_stream_len), n, 1 if wav_quirk else 0, samples.data_ptr(), _stream_ptr(stream)))
+
+
+def add_noise_batch(samples, stream_offset, stream_len, max_stream_len: int, scale_q24, seed: int,
+                    stream_idx_base: int = 0, stream=None) -> None:
+    """Deterministic integer noise in place (same generator as the CPU oracle)."""
+    torch = _torch()
+    _native.require_device()
+    n = int(stream_offset.numel())
+    sc = _as_device_i32(scale_q24, n, samples.device)
+    _native.check(_native.lib().afsk_add_noise_batch(
+        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
+        sc.data_ptr(), n, int(seed) & 0xFFFFFFFF, int(stream_idx_base) & 0xFFFFFFFF,
+        _stream_ptr(stream)))
+    torch.cuda.current_stream().synchronize() if stream is None else stream.synchronize()

@@ -1,0 +1,53 @@
+// Internal header shared by the HIP translation units of libafsk_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afsk {
+
+struct DemodArgs {
+    const int16_t* samples;
+    const int64_t* stream_offset;
+    const int32_t* stream_len;
+    const int32_t* bit_frames;
+    int32_t amp_end;
+    int32_t n_streams;
+    uint8_t* out_bytes;
+    int32_t out_stride;
+    int32_t* out_nbytes;
+    int32_t* out_nbits;
+    int32_t* out_clock_idx;
+    int32_t* out_term_frame;
+    int32_t* out_status;
+};
+
+struct ModulateArgs {
+    const uint8_t* payload;
+    int32_t payload_stride;
+    const int32_t* payload_len;
+    const int32_t* bit_frames;
+    const int32_t* ts_cycles;
+    const int64_t* stream_offset;
+    const int32_t* stream_len;
+    int32_t n_streams;
+    int32_t wav_quirk;
+    int16_t* samples;
+    int32_t chunks;   // 2048-sample chunks per stream (set by the launcher)
+};
+
+struct NoiseArgs {
+    int16_t* samples;
+    const int64_t* stream_offset;
+    const int32_t* stream_len;
+    const int32_t* scale_q24;
+    int32_t n_streams;
+    uint32_t seed;
+    uint32_t stream_idx_base;
+    int32_t chunks;
+};
+
+hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
+hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);
+hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream);
+
+}  // namespace afsk

@@ -1,0 +1,64 @@
+"""Stream sharding across the GPUs of one node.
+
+Streams are independent (nothing in afskmodem.py:354-381 couples two streams),
+so the data path has no collective: rank r demodulates the contiguous range
+``shard_range(n, r, world)`` with its own kernel launches.  The only exchange is
+an optional gather of the decoded bytes + five int32 per stream, done as ONE
+fixed-stride all-gather (RCCL over xGMI with backend "nccl"; gloo on CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_streams: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced [begin, end) of rank's streams."""
+    return (n_streams * rank) // world, (n_streams * (rank + 1)) // world
+
+
+RECORD_I32 = 5   # nbytes, nbits, clock_idx, term_frame, status
+
+
+def pack_records(res):
+    """[n, stride + 20] uint8: decoded bytes row followed by the five int32 (little endian)."""
+    import torch
+    meta = torch.stack([res.nbytes, res.nbits, res.clock_idx, res.term_frame, res.status], dim=1)
+    return torch.cat([res.bytes, meta.contiguous().view(torch.uint8).reshape(meta.shape[0], -1)], dim=1)
+
+
+def unpack_records(rec, stride: int):
+    import torch
+    from .batch import DemodResult
+    meta = rec[:, stride:].contiguous().view(torch.int32).reshape(rec.shape[0], RECORD_I32)
+    return DemodResult(rec[:, :stride].contiguous(), meta[:, 0].contiguous(),
+                       meta[:, 1].contiguous(), meta[:, 2].contiguous(), meta[:, 3].contiguous(),
+                       meta[:, 4].contiguous())
+
+
+def gather_results(res, n_total: int, group=None):
+    """All-gather every rank's DemodResult into one covering all n_total streams.
+
+    Every rank must hold the shard ``shard_range(n_total, rank, world)``.  Shards
+    may differ by one stream, so rows are padded to the largest shard for the
+    single collective and trimmed afterwards.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    stride = int(res.bytes.shape[1])
+    rec = pack_records(res)
+    b, e = shard_range(n_total, rank, world)
+    assert rec.shape[0] == e - b, (rec.shape, b, e)
+    max_rows = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0]
+                   for r in range(world))
+    if rec.shape[0] < max_rows:
+        pad = torch.zeros((max_rows - rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        rec = torch.cat([rec, pad], dim=0)
+    out = torch.empty((world * max_rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        rb, re_ = shard_range(n_total, r, world)
+        parts.append(out[r * max_rows: r * max_rows + (re_ - rb)])
+    return unpack_records(torch.cat(parts, dim=0), stride)

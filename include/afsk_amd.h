@@ -1,0 +1,133 @@
+/*
+ * afsk_amd.h -- C-ABI of libafsk_amd.so: the MI355X (gfx950) batched AFSK
+ * demodulation path behind lavajuno/afskmodem's Receiver.
+ *
+ * The reference has no FFI: its hot path is the private method
+ *     Receiver.__decodeBits(frames) -> str          (afskmodem.py:354-381)
+ * followed by ECC.decode + __bitsToBytes           (afskmodem.py:154-163, 393-399)
+ * called from Receiver.load (:420-430) and Receiver.receive (:402-417).
+ * The entry points below are what a ctypes binding inside afskmodem.py would
+ * bind to replace exactly that span (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *  - every function returns 0 on success or a negative AFSK_E_* code and never
+ *    throws; afsk_last_error() returns the message of the calling thread's
+ *    last failure;
+ *  - the caller owns every buffer.  Unless a function name ends in _host, all
+ *    data pointers are DEVICE pointers of the current HIP device and the call
+ *    is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream);
+ *  - there is no CPU fallback: without a HIP device every compute entry fails
+ *    with AFSK_E_NO_DEVICE.
+ */
+#ifndef AFSK_AMD_H
+#define AFSK_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFSK_ABI_VERSION 1
+
+/* return codes */
+#define AFSK_OK 0
+#define AFSK_E_INVALID_ARG (-1)
+#define AFSK_E_INVALID_BAUD (-2) /* bit_frames not a multiple of 4 or 2*bf >= 4096      */
+#define AFSK_E_NO_DEVICE (-3)
+#define AFSK_E_HIP (-4)          /* a HIP runtime call failed, see afsk_last_error      */
+
+/* per-stream status written to out_status (reference behaviour in brackets) */
+#define AFSK_ST_OK 0
+#define AFSK_ST_TOO_SHORT 1 /* len < 4096 [__recoverClockIndex -> -1 -> "" , :323-325] */
+#define AFSK_ST_NO_DATA 2   /* no terminator / zero bits [bits == "" -> b"", :422-424]  */
+#define AFSK_ST_INVALID_BAUD 3 /* bit_frames[s] rejected (host wrappers raise before launch) */
+
+/* Fixed constants of the reference that the kernels compile in. */
+#define AFSK_SAMPLE_RATE 48000 /* :69,71,187,233,260,277 */
+#define AFSK_SYNC_WINDOW 4096  /* :323,327                */
+#define AFSK_DEAD_ZONE 512     /* :290-292                */
+#define AFSK_TAIL_SILENCE 4800 /* :468                    */
+
+int afsk_version(void);
+/* Copies the calling thread's last error message (NUL terminated, truncated to
+ * cap) and returns its full length. */
+int afsk_last_error(char *buf, int cap);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int afsk_device_count(void);
+/* hipStreamSynchronize(hip_stream). */
+int afsk_sync(void *hip_stream);
+
+/*
+ * Replaces Receiver.__decodeBits (:354-381) + ECC.decode (:154-163) +
+ * __bitsToBytes (:393-399) for n_streams independent streams at once.
+ *
+ *  samples        int16 mono 48 kHz, all streams in one allocation
+ *  stream_offset  [n] first sample of stream s, in samples from `samples`
+ *  stream_len     [n] length of stream s in samples (>= 0, < 2^30)
+ *  bit_frames     [n] 48000 / baud of stream s (Receiver.__init__ :277);
+ *                 must be a multiple of 4 with 2*bit_frames < 4096
+ *  amp_end_threshold  Receiver(amp_end_threshold=...) (:276), squelch of :375
+ *  out_bytes      [n, out_stride] decoded payload bytes (row s, first
+ *                 min(out_nbytes[s], out_stride) bytes are written)
+ *  out_nbytes     [n] number of decoded bytes (may exceed out_stride: the row
+ *                 was then truncated; size rows as stream_len/(14*bf)+1)
+ *  out_nbits      [n] coded bits demodulated incl. ECC (debug line :380)
+ *  out_clock_idx  [n] recovered clock index (:338), -1 when too short
+ *  out_term_frame [n] frame index after the training terminator (:368), -1
+ *                 when too short
+ *  out_status     [n] AFSK_ST_*
+ *
+ * Results are bit-exact with the reference for every input (integer path).
+ */
+int afsk_demod_batch(const int16_t *samples, const int64_t *stream_offset,
+                     const int32_t *stream_len, const int32_t *bit_frames,
+                     int32_t amp_end_threshold, int32_t n_streams, uint8_t *out_bytes,
+                     int32_t out_stride, int32_t *out_nbytes, int32_t *out_nbits,
+                     int32_t *out_clock_idx, int32_t *out_term_frame, int32_t *out_status,
+                     void *hip_stream);
+
+/*
+ * Same operation on HOST buffers: allocates device scratch, copies in, runs the
+ * HIP kernel, copies out, synchronises.  This is the PCIe-inclusive convenience
+ * path a single Receiver.load() uses; it is not the benchmarked entry.
+ */
+int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
+                          const int64_t *stream_offset, const int32_t *stream_len,
+                          const int32_t *bit_frames, int32_t amp_end_threshold,
+                          int32_t n_streams, uint8_t *out_bytes, int32_t out_stride,
+                          int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
+                          int32_t *out_term_frame, int32_t *out_status);
+
+/*
+ * On-device input synthesis: Transmitter.__getFrames (:452-469) with ECC.encode
+ * (:166-175) and, when wav_quirk != 0, SoundOutput.__convertFrames' decimate-by-2
+ * + duplicate (:239-244), written to samples[stream_offset[s] .. +stream_len[s])
+ * (truncated, or zero padded after the 4800-sample tail).
+ *
+ *  payload      uint8 [n, payload_stride]; payload_len [n] bytes used per row
+ *  ts_cycles    [n] int(baud * training_time / 2)   (:438)
+ *  max_stream_len  host-side upper bound of stream_len[] (sizes the grid)
+ */
+int afsk_modulate_batch(const uint8_t *payload, int32_t payload_stride,
+                        const int32_t *payload_len, const int32_t *bit_frames,
+                        const int32_t *ts_cycles, const int64_t *stream_offset,
+                        const int32_t *stream_len, int32_t max_stream_len, int32_t n_streams,
+                        int32_t wav_quirk, int16_t *samples, void *hip_stream);
+
+/*
+ * Deterministic additive noise (build-owned test/benchmark input generator, no
+ * reference counterpart): per sample an Irwin-Hall sum of 16 uniform u16 drawn
+ * from a counter hash of (seed, stream_idx_base + s, sample index), centred,
+ * multiplied by scale_q24[s] / 2^24, added and clipped to int16.  Integer-only,
+ * so the CPU oracle's generator produces identical samples.
+ */
+int afsk_add_noise_batch(int16_t *samples, const int64_t *stream_offset,
+                         const int32_t *stream_len, int32_t max_stream_len,
+                         const int32_t *scale_q24, int32_t n_streams, uint32_t seed,
+                         uint32_t stream_idx_base, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""world_size-2 gloo test of the shard + gather path (CPU tensors stand in for HBM)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from afskmodem_amd import dist as adist
+from afskmodem_amd.batch import DemodResult
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_result(begin, end, stride):
+    n = end - begin
+    idx = torch.arange(begin, end, dtype=torch.int32)
+    b = (idx[:, None] * 3 + torch.arange(stride, dtype=torch.int32)[None, :]) % 251
+    return DemodResult(b.to(torch.uint8), idx % 35, idx * 14, idx % 4096, idx + 24160, idx % 3)
+
+
+def _worker(rank, world, port, n_total, stride, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = adist.shard_range(n_total, rank, world)
+    full = adist.gather_results(_fake_result(b, e, stride), n_total)
+    want = _fake_result(0, n_total, stride)
+    ok = all(torch.equal(getattr(full, f), getattr(want, f))
+             for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"))
+    q.put((rank, ok, int(full.bytes.shape[0])))
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 4096, 524288, 1001):
+        for world in (1, 2, 3, 8):
+            ranges = [adist.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for (b0, e0), (b1, e1) in zip(ranges, ranges[1:]):
+                assert e0 == b1
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    r = _fake_result(5, 37, 40)
+    rec = adist.pack_records(r)
+    assert rec.shape == (32, 40 + 20)
+    back = adist.unpack_records(rec, 40)
+    for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"):
+        assert torch.equal(getattr(back, f), getattr(r, f))
+
+
+@pytest.mark.parametrize("n_total", [64, 33])
+def test_gather_world2_gloo(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, 40, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(ok and rows == n_total for _, ok, rows in res)

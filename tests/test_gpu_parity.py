@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+ (a) the committed golden vectors produced by the reference itself, and
+ (b) the CPU oracle on the same seeded inputs,
+bit-exact in every output (bytes, nbytes, nbits, clock index, terminator frame,
+status).  Integer path: tolerance is zero."""
+import numpy as np
+import pytest
+
+import afskmodem_amd as afskmodem
+from afskmodem_amd import _native, batch, synth
+from oracle import afsk_oracle as O
+from tests.golden_inputs import build_input
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    # fail loudly: GPU tests must exercise the HIP library, never a fallback
+    assert _native.device_count() > 0, "no HIP device: GPU tests need an MI355X"
+    assert torch.cuda.is_available()
+    return torch
+
+
+def assert_same(got, want, tag=""):
+    """got: HostDemodResult, want: oracle dict."""
+    for f in FIELDS:
+        g, w = getattr(got, f), want[f]
+        bad = np.nonzero(g != w)[0]
+        assert bad.size == 0, f"{tag} {f}: {bad.size} streams differ, first {bad[:5]}: got {g[bad[:5]]} want {w[bad[:5]]}"
+    stride = min(got.bytes.shape[1], want["bytes"].shape[1])
+    n = np.minimum(want["nbytes"], stride)
+    col = np.arange(stride)[None, :]
+    mask = col < n[:, None]
+    diff = (got.bytes[:, :stride] != want["bytes"][:, :stride]) & mask
+    bad = np.nonzero(diff.any(axis=1))[0]
+    assert bad.size == 0, f"{tag} bytes: {bad.size} streams differ, first {bad[:5]}"
+
+
+def device_demod(torch, flat, off, ln, bf, amp_end=14000, stride=None):
+    dev = "cuda:0"
+    x = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int16)).to(dev)
+    o = torch.from_numpy(np.ascontiguousarray(off, dtype=np.int64)).to(dev)
+    l = torch.from_numpy(np.ascontiguousarray(ln, dtype=np.int32)).to(dev)
+    if stride is None:
+        stride = batch.out_stride_for(int(np.max(ln)), int(np.min(bf)))
+    res = batch.demod_batch(x, o, l, np.asarray(bf, np.int32), amp_end, out_stride=stride)
+    torch.cuda.synchronize()
+    return res.cpu()
+
+
+# ------------------------------------------------------------------ golden vectors
+
+
+def test_golden_cases_host_entry(golden, torch_cuda):
+    """Every reference-generated decode case through afsk_demod_batch_host (ragged batch)."""
+    cases = golden["decode_cases"]
+    xs = [build_input(c) for c in cases]
+    for amp_end in sorted({c["amp_end"] for c in cases}):
+        idx = [i for i, c in enumerate(cases) if c["amp_end"] == amp_end]
+        res = batch.demod_host_arrays([xs[i] for i in idx],
+                                      [48000 // cases[i]["baud"] for i in idx], amp_end)
+        pl = res.payloads()
+        for j, i in enumerate(idx):
+            c = cases[i]
+            assert res.clock_idx[j] == c["clock_idx"], c["tag"]
+            assert res.term_frame[j] == c["term_frame"], c["tag"]
+            assert res.nbits[j] == c["nbits"], c["tag"]
+            assert res.nbytes[j] == c["nbytes"], c["tag"]
+            assert pl[j].hex() == c["bytes_hex"], c["tag"]
+            want = 1 if c["clock_idx"] == -1 else (2 if c["nbits"] == 0 else 0)
+            assert res.status[j] == want, c["tag"]
+
+
+def test_golden_cases_device_entry(golden, torch_cuda):
+    """Same cases through afsk_demod_batch on device tensors, one mixed-baud launch."""
+    cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]
+    xs = [build_input(c) for c in cases]
+    ln = np.array([len(x) for x in xs], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    bf = np.array([48000 // c["baud"] for c in cases], np.int32)
+    res = device_demod(torch_cuda, np.concatenate(xs), off, ln, bf)
+    pl = res.payloads()
+    for j, c in enumerate(cases):
+        got = (int(res.clock_idx[j]), int(res.term_frame[j]), int(res.nbits[j]), pl[j].hex())
+        assert got == (c["clock_idx"], c["term_frame"], c["nbits"], c["bytes_hex"]), c["tag"]
+
+
+def test_receiver_load_readme_roundtrip(golden, torch_cuda, tmp_path):
+    """README.md:47-66 assertion through the drop-in API (Transmitter.save -> Receiver.load)."""
+    afskmodem.LOG_LEVEL = 5
+    fn = str(tmp_path / "afsk.wav")
+    afskmodem.Transmitter(1200).save("Héellóo World!", fn)
+    assert afskmodem.Receiver(1200).load(fn, True) == golden["readme_roundtrip"]
+    # config #1: Hello World! at 1200 baud
+    afskmodem.Transmitter(1200).save("Hello World!", fn)
+    assert afskmodem.Receiver(1200).load(fn) == "Hello World!"
+    assert afskmodem.Receiver(1200).load(fn, False) == b"Hello World!"
+    # return conventions: b"" on no data even with string=True; invalid utf-8 raises
+    afskmodem.Transmitter(1200).save(b"", fn)
+    assert afskmodem.Receiver(1200).load(fn, True) == b""
+    afskmodem.Transmitter(1200).save(b"\xff\xfe\xfd", fn)
+    assert afskmodem.Receiver(1200).load(fn, False) == b"\xff\xfe\xfd"
+    with pytest.raises(UnicodeDecodeError):
+        afskmodem.Receiver(1200).load(fn, True)
+    for baud in (300, 2400, 600):
+        afskmodem.Transmitter(baud).save("Hello World!", fn)
+        assert afskmodem.Receiver(baud).load(fn) == "Hello World!"
+    afskmodem.LOG_LEVEL = 0
+
+
+def test_invalid_baud_raises_like_reference(torch_cuda):
+    x = afskmodem.Transmitter(1200).wav_samples(b"Hi!")
+    with pytest.raises(Exception, match="different lengths"):
+        afskmodem.Receiver(4800).decode_frames(x)
+    with pytest.raises(IndexError):
+        afskmodem.Receiver(20).decode_frames(x)
+    assert afskmodem.Receiver(4800).decode_frames(x[:4000]) == b""   # too short: no raise
+
+
+# ------------------------------------------------------------- seeded batches vs oracle
+
+
+def synth_batch(torch, n, bauds, seed, total=48000, training_time=0.5, snr_db=None,
+                payload_len=None, wav_quirk=True):
+    """Modulate n streams on the GPU; returns device tensors + host copies."""
+    dev = "cuda:0"
+    bauds = np.asarray([bauds[i % len(bauds)] for i in range(n)], np.int32)
+    bf = (48000 // bauds).astype(np.int32)
+    plen = np.array([payload_len if payload_len is not None else synth.ONE_SECOND_PAYLOAD[int(b)]
+                     for b in bauds], np.int32)
+    stride = int(plen.max()) if n else 1
+    payload = synth.payload_bytes(seed, 0, n, max(stride, 1))
+    ts = np.array([synth.ts_cycles_for(int(b), training_time) for b in bauds], np.int32)
+    off = (np.arange(n, dtype=np.int64) * total)
+    ln = np.full(n, total, np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    samples = torch.empty(n * total, dtype=torch.int16, device=dev)
+    d_off, d_ln, d_bf = t(off), t(ln), t(bf)
+    batch.modulate_batch(t(payload), t(plen), d_bf, t(ts), d_off, d_ln, total, samples, wav_quirk)
+    if snr_db is not None:
+        q = np.asarray([synth.snr_to_scale_q24(s) for s in np.broadcast_to(snr_db, (n,))], np.int32)
+        batch.add_noise_batch(samples, d_off, d_ln, total, q, seed=seed + 1, stream_idx_base=0)
+    else:
+        q = None
+    torch.cuda.synchronize()
+    return dict(samples=samples, off=d_off, ln=d_ln, bf=d_bf, h_off=off, h_ln=ln, h_bf=bf,
+                payload=payload, plen=plen, ts=ts, q=q, total=total)
+
+
+def test_modulator_and_noise_match_oracle(torch_cuda):
+    torch = torch_cuda
+    b = synth_batch(torch, 48, (300, 1200, 2400), seed=11, snr_db=None)
+    want = O.modulate_batch(b["payload"], b["plen"], b["h_bf"], b["ts"], b["h_off"], b["h_ln"],
+                            48 * b["total"], True)
+    got = b["samples"].cpu().numpy()
+    assert np.array_equal(got, want)
+    # without the wav quirk = ideal frames
+    b2 = synth_batch(torch, 6, (2400,), seed=12, wav_quirk=False)
+    want2 = O.modulate_batch(b2["payload"], b2["plen"], b2["h_bf"], b2["ts"], b2["h_off"],
+                             b2["h_ln"], 6 * b2["total"], False)
+    assert np.array_equal(b2["samples"].cpu().numpy(), want2)
+    # noise generator: identical integers on CPU and GPU
+    snr = [30, 10, 5, 0]
+    b3 = synth_batch(torch, 4, (1200,), seed=13, snr_db=snr)
+    clean = O.modulate_batch(b3["payload"], b3["plen"], b3["h_bf"], b3["ts"], b3["h_off"],
+                             b3["h_ln"], 4 * b3["total"], True).reshape(4, -1)
+    noisy = b3["samples"].cpu().numpy().reshape(4, -1)
+    for s in range(4):
+        assert np.array_equal(noisy[s], O.add_noise(clean[s], 14, s, int(b3["q"][s]))), s
+
+
+@pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])
+def test_clean_batches_vs_oracle(torch_cuda, n, bauds):
+    """Config #2 / #3 shapes at test size: every output equals the CPU oracle's, and the
+    decoded payload equals what was modulated (round trip)."""
+    torch = torch_cuda
+    pl = None if all(b in synth.ONE_SECOND_PAYLOAD for b in bauds) else 3
+    b = synth_batch(torch, n, bauds, seed=21, payload_len=pl)
+    stride = batch.out_stride_for(b["total"], int(b["h_bf"].min()))
+    res = batch.demod_batch(b["samples"], b["off"], b["ln"], b["h_bf"], 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    want = O.demod_batch(b["samples"].cpu().numpy(), b["h_off"], b["h_ln"], b["h_bf"], 14000,
+                         out_stride=stride, n_threads=8)
+    assert_same(got, want, f"clean {bauds}")
+    for s, data in enumerate(got.payloads()):
+        assert data == b["payload"][s, : b["plen"][s]].tobytes(), s
+
+
+def test_noise_sweep_vs_oracle(torch_cuda):
+    """Config #4 shape at test size: SNR 30 -> 0 dB, GPU and CPU results coincide exactly,
+    including squelch over-read and false terminators at low SNR."""
+    torch = torch_cuda
+    snrs = [30, 25, 20, 15, 10, 7, 5, 3, 0]
+    n = 64 * len(snrs)
+    snr = np.repeat(snrs, 64)
+    b = synth_batch(torch, n, (1200,), seed=31, snr_db=snr)
+    stride = batch.out_stride_for(b["total"], 40)
+    got = batch.demod_batch(b["samples"], b["off"], b["ln"], 40, 14000, out_stride=stride).cpu()
+    want = O.demod_batch(b["samples"].cpu().numpy(), b["h_off"], b["h_ln"], b["h_bf"], 14000,
+                         out_stride=stride, n_threads=8)
+    assert_same(got, want, "noise sweep")
+    # the sweep must actually exercise the hard cases
+    assert (got.clock_idx != 0).any() and (got.nbits > 476).any()
+    ber_ok = [all(got.payloads()[i][:34] == b["payload"][i, :34].tobytes()
+                  for i in range(k * 64, k * 64 + 64)) for k in range(len(snrs))]
+    assert ber_ok[0] and ber_ok[4]          # 30 dB and 10 dB decode error-free
+    for baud, bf in ((300, 160), (2400, 20)):
+        bb = synth_batch(torch, 96, (baud,), seed=32 + bf, snr_db=np.repeat([12, 6, 2], 32))
+        st = batch.out_stride_for(bb["total"], bf)
+        g = batch.demod_batch(bb["samples"], bb["off"], bb["ln"], bf, 14000, out_stride=st).cpu()
+        w = O.demod_batch(bb["samples"].cpu().numpy(), bb["h_off"], bb["h_ln"], bb["h_bf"], 14000,
+                          out_stride=st, n_threads=8)
+        assert_same(g, w, f"noise {baud}")
+
+
+def test_ragged_unaligned_and_edge_lengths(torch_cuda):
+    """Ragged lengths, odd sample offsets (2-byte aligned streams), the 4096 boundary,
+    streams with no tail silence, empty batch, truncating out_stride."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    tx = afskmodem.Transmitter(1200, 0.1)
+    pieces, bf = [], []
+    lens_wanted = [0, 1, 4000, 4095, 4096, 4097, 4136, 4137, 5000, 9999, 12345, 20001]
+    for i, L in enumerate(lens_wanted):
+        w = tx.wav_samples(rng.integers(0, 256, 5, dtype=np.uint8).tobytes())
+        lead = rng.integers(0, 300)
+        w = np.concatenate([np.zeros(lead, np.int16), w])
+        pieces.append(w[:L] if L <= len(w) else np.concatenate([w, np.zeros(L - len(w), np.int16)]))
+        bf.append(40)
+    for baud in (300, 2400, 600):      # no tail: final symbol ends at the buffer end
+        t = afskmodem.Transmitter(baud, 0.1)
+        fr = t.frames(b"xyz")[:-4800]
+        for extra in (0, 1, 2, 3, 5):
+            pieces.append(np.concatenate([fr, np.zeros(extra, np.int16)]))
+            bf.append(48000 // baud)
+    # odd gaps between streams so that bases are only 2-byte aligned
+    gaps = [1, 3, 0, 7, 1, 1, 5, 0, 9, 1, 3, 1] + [1] * (len(pieces) - 12)
+    flat, off = [], []
+    pos = 0
+    for p, g in zip(pieces, gaps):
+        flat.append(rng.integers(-30000, 30000, g).astype(np.int16)); pos += g
+        off.append(pos); flat.append(p); pos += len(p)
+    flat.append(np.zeros(3, np.int16))
+    flat = np.concatenate(flat)
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.array(off, np.int64)
+    bf = np.array(bf, np.int32)
+    got = device_demod(torch, flat, off, ln, bf, stride=64)
+    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=64)
+    assert_same(got, want, "ragged")
+    assert (got.status == 1).sum() == 4 and (got.status == 0).sum() >= 10
+    # truncating stride: nbytes still reports the full count, row holds the prefix
+    got2 = device_demod(torch, flat, off, ln, bf, stride=4)
+    assert np.array_equal(got2.nbytes, want["nbytes"])
+    n4 = np.minimum(want["nbytes"], 4)
+    for s in range(len(ln)):
+        assert got2.bytes[s, : n4[s]].tobytes() == want["bytes"][s, : n4[s]].tobytes()
+    # empty batch
+    assert batch.demod_host_arrays([], 40).nbytes.size == 0
+
+
+def test_squelch_thresholds_and_long_stream(torch_cuda):
+    torch = torch_cuda
+    b = synth_batch(torch, 32, (1200,), seed=41, snr_db=np.repeat([40, 8], 16))
+    h = b["samples"].cpu().numpy()
+    for amp_end in (0, -5, 1, 14000, 20000, 32767, 32768, 40000, 100000):
+        stride = 400
+        got = batch.demod_batch(b["samples"], b["off"], b["ln"], 40, amp_end, out_stride=stride).cpu()
+        want = O.demod_batch(h, b["h_off"], b["h_ln"], b["h_bf"], amp_end, out_stride=stride, n_threads=8)
+        assert_same(got, want, f"amp_end {amp_end}")
+    # one long stream (20 s, 2400 baud, 1500-byte payload): many DMA rounds, many bytes
+    t = afskmodem.Transmitter(2400, 0.5)
+    data = np.random.default_rng(3).integers(0, 256, 1500, dtype=np.uint8).tobytes()
+    w = t.wav_samples(data)
+    got = batch.demod_host_arrays([w, w[: len(w) // 2]], 20)
+    want = O.demod_batch(np.concatenate([w, w[: len(w) // 2]]), [0, len(w)],
+                         [len(w), len(w) // 2], [20, 20], 14000, out_stride=got.bytes.shape[1])
+    assert_same(got, want, "long")
+    assert got.payloads()[0] == data
+
+
+def test_full_size_config2_roundtrip(torch_cuda):
+    """BASELINE config #2 at full size (4096 x 1 s, 1200 baud): decoded == modulated payloads
+    for every stream (size-independent round-trip property) + oracle on a 256-stream sample."""
+    torch = torch_cuda
+    n = 4096
+    b = synth_batch(torch, n, (1200,), seed=2024)
+    stride = batch.out_stride_for(48000, 40)
+    res = batch.demod_batch(b["samples"], b["off"], b["ln"], 40, 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    assert (got.status == 0).all() and (got.nbytes == 34).all() and (got.nbits == 476).all()
+    assert (got.clock_idx == 0).all() and (got.term_frame == 24160).all()
+    assert np.array_equal(got.bytes[:, :34], b["payload"][:, :34])
+    sel = np.arange(0, n, 16)
+    h = b["samples"].cpu().numpy().reshape(n, -1)[sel].reshape(-1)
+    want = O.demod_batch(h, np.arange(len(sel), dtype=np.int64) * 48000,
+                         np.full(len(sel), 48000, np.int32), np.full(len(sel), 40, np.int32),
+                         14000, out_stride=stride, n_threads=8)
+    sub = batch.HostDemodResult(got.bytes[sel], got.nbytes[sel], got.nbits[sel],
+                                got.clock_idx[sel], got.term_frame[sel], got.status[sel])
+    assert_same(sub, want, "config2 sample")

@@ -1,0 +1,189 @@
+"""CPU-only tests of the host-side mirror of the reference API (afskmodem_amd.modem),
+the synthetic-workload helpers, and the C-ABI library surface (no compute calls)."""
+import ctypes
+import hashlib
+import io
+import os
+import re
+import contextlib
+
+import numpy as np
+import pytest
+
+import afskmodem_amd as afskmodem
+from afskmodem_amd import _native, batch, synth
+from oracle import afsk_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha_i16(a):
+    return hashlib.sha256(np.asarray(a, dtype="<i2").tobytes()).hexdigest()
+
+
+def test_templates_match_reference(golden):
+    for baud, t in golden["templates"].items():
+        b = int(baud)
+        assert afskmodem.Waveforms.getSpaceTone(b) == t["space"]
+        assert afskmodem.Waveforms.getMarkTone(b) == t["mark"]
+        assert afskmodem.Waveforms.getTrainingCycle(b) == t["training"]
+
+
+def test_constructor_errors_match_reference(golden):
+    for baud, e in golden["baud_validity"].items():
+        b = int(baud)
+        if e["construct"] != "ok":
+            with pytest.raises(Exception, match="Invalid baud rate"):
+                afskmodem.Receiver(b)
+            with pytest.raises(Exception, match="Invalid baud rate"):
+                afskmodem.Transmitter(b)
+        else:
+            r = afskmodem.Receiver(b)
+            afskmodem.Transmitter(b)
+            rt = e["roundtrip"]
+            if "different lengths" in rt:
+                with pytest.raises(Exception, match="different lengths"):
+                    r.check_decodable(48000)
+            elif "IndexError" in rt:
+                with pytest.raises(IndexError):
+                    r.check_decodable(48000)
+            else:
+                r.check_decodable(48000)
+            r.check_decodable(100)   # too short never raises (ref:323-325)
+
+
+def test_primitives(golden):
+    for p in golden["primitives"]:
+        assert afskmodem.Waveforms.getDiff(p["a"], p["b"]) == p["diff"]
+        assert afskmodem.Waveforms.getAmplitude(p["a"]) == p["amp_a"]
+    with pytest.raises(Exception, match="different lengths"):
+        afskmodem.Waveforms.getDiff([1, 2], [1])
+
+
+def test_ecc(golden):
+    e = golden["ecc"]
+    for k, v in e["codewords"].items():
+        assert afskmodem.ECC.encode(k) == v
+    for k, v in e["decode_table"].items():
+        assert afskmodem.ECC.decode(k) == v
+    for k, v in e["short"].items():
+        assert afskmodem.ECC.encode(k) == v["encode"]
+        assert afskmodem.ECC.decode(k) == v["decode"]
+
+
+def test_transmitter_frames_and_wav(golden, tmp_path):
+    for c in golden["frames"]:
+        t = afskmodem.Transmitter(c["baud"], c["training_time"])
+        data = bytes.fromhex(c["payload_hex"])
+        fr = t.frames(data)
+        assert len(fr) == c["n_frames"]
+        assert sha_i16(fr) == c["frames_sha256"]
+        w = t.wav_samples(data)
+        assert len(w) == c["n_wav"] and sha_i16(w) == c["wav_sha256"]
+        assert synth.frames_needed(t.bit_frames, t.ts_cycles, len(data)) == c["n_frames"]
+    # .wav file bytes identical to the reference's writer (README example payload)
+    fn = str(tmp_path / "afsk.wav")
+    afskmodem.Transmitter(1200).save("Héellóo World!", fn)
+    with open(fn, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == golden["readme_wav_file_sha256"]
+    assert afskmodem.SoundInput.loadFromFile(fn) == afskmodem.Transmitter(1200).wav_samples(
+        "Héellóo World!").tolist()
+
+
+def test_log_format_and_level():
+    afskmodem.LOG_LEVEL = 2
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        log = afskmodem.Log("afskmodem.Receiver")
+        log.debug("hidden")
+        log.info("hidden")
+        log.warn("No data.")
+    afskmodem.LOG_LEVEL = 0
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 1
+    assert re.fullmatch(r"\d{4}-\d\d-\d\d \d\d:\d\d:\d\d \[ WARN \]  afskmodem\.Receiver {6}: No data\.",
+                        lines[0])
+
+
+def test_synth_helpers():
+    p1 = synth.payload_bytes(7, 0, 16, 34)
+    p2 = synth.payload_bytes(7, 8, 8, 34)
+    assert p1.shape == (16, 34) and p1.dtype == np.uint8
+    assert np.array_equal(p1[8:], p2)               # counter based: independent of batch split
+    assert len(np.unique(p1)) > 100
+    for baud, nb in synth.ONE_SECOND_PAYLOAD.items():
+        n = synth.frames_needed(48000 // baud, synth.ts_cycles_for(baud), nb)
+        assert n <= 48000 and n == len(O.get_frames(bytes(nb), baud))
+    assert synth.snr_to_scale_q24(10) == 2297180 or synth.snr_to_scale_q24(10) > 0
+
+
+def test_snr_scale_matches_golden_generator(golden):
+    for c in golden["decode_cases"]:
+        g = c["gen"]
+        if g and g["kind"] == "wav_noise":
+            assert synth.snr_to_scale_q24(g["snr_db"]) == g["scale_q24"]
+
+
+def test_validate_bit_frames():
+    batch.validate_bit_frames([40, 20, 160])
+    with pytest.raises(Exception, match="Invalid baud rate"):
+        batch.validate_bit_frames([7])
+    with pytest.raises(Exception, match="different lengths"):
+        batch.validate_bit_frames([10])
+    with pytest.raises(IndexError):
+        batch.validate_bit_frames([2400])
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libafsk_amd.so loads and exports every function include/afsk_amd.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "afsk_amd.h")).read()
+    declared = set(re.findall(r"^int (afsk_\w+)\(", hdr, flags=re.M))
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    lib = _native.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.afsk_version() == 1
+    assert int(re.search(r"#define AFSK_ABI_VERSION (\d+)", hdr).group(1)) == lib.afsk_version()
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the product path raises; it never falls back to a CPU implementation."""
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_native.AfskNativeError) as ei:
+        afskmodem.Receiver(1200).decode_frames(np.zeros(5000, np.int16))
+    assert ei.value.code == _native.E_NO_DEVICE
+    with pytest.raises(_native.AfskNativeError):
+        batch.demod_host_arrays([np.zeros(5000, np.int16)], 40)
+
+
+def test_cabi_argument_checks():
+    lib = _native.lib()
+    rc = lib.afsk_demod_batch(None, None, None, None, 14000, -1, None, 0, None, None, None, None,
+                              None, None)
+    assert rc == _native.E_INVALID_ARG and "negative" in _native.last_error()
+    rc = lib.afsk_demod_batch(None, None, None, None, 14000, 4, None, 0, None, None, None, None,
+                              None, None)
+    assert rc == _native.E_INVALID_ARG and "null" in _native.last_error()
+    assert lib.afsk_demod_batch(None, None, None, None, 14000, 0, None, 0, None, None, None, None,
+                                None, None) == 0
+    # host entry validates bit_frames before touching the device
+    x = np.zeros(8, np.int16)
+    off = np.zeros(1, np.int64); ln = np.array([8], np.int32); bf = np.array([10], np.int32)
+    ob = np.zeros(4, np.uint8); i32 = [np.zeros(1, np.int32) for _ in range(5)]
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))  # noqa: E731
+    rc = lib.afsk_demod_batch_host(p(x, ctypes.c_int16), 8, p(off, ctypes.c_int64),
+                                   p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
+                                   p(ob, ctypes.c_uint8), 4, *(p(a, ctypes.c_int32) for a in i32))
+    assert rc == _native.E_INVALID_BAUD
+
+
+def test_product_package_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under afskmodem_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "afskmodem_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+                assert "libafsk_oracle" not in text and "afsk_oracle.h" not in text, fn
