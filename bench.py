@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- batched AFSK demodulation throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (afsk_demod_batch: sync search + symbol
+correlator + squelch + Hamming decode + byte pack) over one batch of synthetic
+streams that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: 4096 Transmitter-generated, clean, 1 s, 1200-baud streams per GPU
+(weak scaling: every rank demodulates its own 4096-stream shard; for N > 1 the
+decoded records of each step are all-gathered over RCCL on a side stream,
+overlapped with the next step's kernel).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (HBM-read bound; algorithmic bytes / HIP-event kernel time) and, at
+N = 1, `cpu_baseline` (the CPU oracle -- a C port of the reference -- timed on
+this box's host cores on a bounded sample, also used as the match-rate checker).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (streams per GPU, bauds cycled over streams, snr_db or None, description)
+    "config2": (4096, (1200,), None, "configs[1]: 4096 streams x 1 s @1200 baud, clean, per GPU"),
+    "config3": (65536, (300, 1200, 2400), None, "configs[2]: 65536 streams x 1 s mixed baud {300,1200,2400}, clean, per GPU"),
+    "config4": (65536, (1200,), 10.0, "configs[3]: 65536 streams x 1 s @1200 baud, additive noise SNR 10 dB, per GPU"),
+    "config5": (65536, (1200,), None, "configs[4]: 65536 streams x 1 s @1200 baud, clean, per GPU (524288 on 8)"),
+}
+STREAM_LEN = 48000
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-streams", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from afskmodem_amd import _native, batch, synth
+    from afskmodem_amd import dist as adist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    _native.require_device()          # no GPU -> loud failure, never a CPU fallback
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_local, bauds, snr_db, desc = WORKLOADS[args.workload]
+    if args.streams > 0:
+        n_local = args.streams
+    n_total = n_local * world
+    first = rank * n_local          # this rank's contiguous shard (dist.shard_range of n_total)
+    assert adist.shard_range(n_total, rank, world) == (first, first + n_local)
+
+    # ---- synthesise this rank's shard on the device (not timed)
+    gidx = np.arange(first, first + n_local)
+    baud_arr = np.asarray([bauds[i % len(bauds)] for i in gidx], np.int32)
+    bf_h = (48000 // baud_arr).astype(np.int32)
+    plen_h = np.asarray([synth.ONE_SECOND_PAYLOAD[int(b)] for b in baud_arr], np.int32)
+    pstride = int(plen_h.max())
+    payload_h = synth.payload_bytes(2024, first, n_local, pstride)
+    ts_h = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_arr], np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    samples = torch.empty(n_local * STREAM_LEN, dtype=torch.int16, device=dev)
+    off, ln = batch.uniform_layout(n_local, STREAM_LEN, dev)
+    bf = t(bf_h)
+    batch.modulate_batch(t(payload_h), t(plen_h), bf, t(ts_h), off, ln, STREAM_LEN, samples, True)
+    if snr_db is not None:
+        batch.add_noise_batch(samples, off, ln, STREAM_LEN, synth.snr_to_scale_q24(snr_db),
+                              seed=99, stream_idx_base=first)
+    torch.cuda.synchronize()
+
+    stride = batch.out_stride_for(STREAM_LEN, int(bf_h.min()))
+    outs = [batch.alloc_result(n_local, stride, dev) for _ in range(2)]   # double buffer
+
+    lib = _native.lib()
+    cur = torch.cuda.current_stream()
+    sptr = C.c_void_p(cur.cuda_stream)
+
+    def launch(o) -> None:
+        rc = lib.afsk_demod_batch(samples.data_ptr(), off.data_ptr(), ln.data_ptr(), bf.data_ptr(),
+                                  14000, n_local, o.bytes.data_ptr(), stride, o.nbytes.data_ptr(),
+                                  o.nbits.data_ptr(), o.clock_idx.data_ptr(),
+                                  o.term_frame.data_ptr(), o.status.data_ptr(), sptr)
+        if rc != 0:
+            _native.check(rc)
+
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    ready_ev = [torch.cuda.Event() for _ in range(2)]
+    done_ev = [torch.cuda.Event() for _ in range(2)]
+    gathered = None
+
+    def step(i: int) -> None:
+        """Launch the demod of step i; for N > 1 all-gather its records on the comm stream so
+        that the gather of step i overlaps the kernel of step i+1 (double-buffered outputs)."""
+        nonlocal gathered
+        b = i & 1
+        o = outs[b]
+        if comm is not None and i >= 2:
+            cur.wait_event(done_ev[b])     # gather of step i-2 has finished reading buffer b
+        launch(o)
+        if comm is not None:
+            ready_ev[b].record(cur)
+            comm.wait_event(ready_ev[b])
+            with torch.cuda.stream(comm):
+                gathered = adist.gather_results(o, n_total)
+                done_ev[b].record(comm)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(cur)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(cur)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)   # avg launch duration incl. gaps
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- check + algorithmic bytes from the last step's outputs
+    res = outs[(args.steps - 1) & 1].cpu() if args.steps > 0 else outs[0].cpu()
+    got_payloads = res.payloads()
+    if snr_db is None:
+        ok = sum(got_payloads[s] == payload_h[s, : plen_h[s]].tobytes() for s in range(n_local))
+        roundtrip_rate = ok / n_local
+    else:
+        roundtrip_rate = None
+    # samples the reference must read: up to and including the squelch-triggering symbol
+    active = np.minimum(np.maximum(res.term_frame.astype(np.int64)
+                                   + (res.nbits.astype(np.int64) + 1) * bf_h, 4096), STREAM_LEN)
+    out_bytes_alg = int(np.minimum(res.nbytes, stride).sum()) + 20 * n_local
+    alg_bytes = int(2 * active.sum()) + out_bytes_alg
+    achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("workload") == args.workload and tj.get("streams") == n_local:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    samples_per_step = n_total * STREAM_LEN
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "Msamples/s demodulated (batched 48 kHz streams) + decoded-byte match rate vs CPU ref",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int16",
+        "data": "synthetic",
+        "config": {"workload": desc, "streams_per_gpu": n_local, "streams_total": n_total,
+                   "stream_len": STREAM_LEN, "bauds": list(bauds), "snr_db": snr_db,
+                   "parallelism": f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": round(kernel_ms, 5),
+                     "full_buffer_gbs": round((2 * n_local * STREAM_LEN) / (kernel_ms * 1e-3) / 1e9, 1)},
+        "roundtrip_match_rate": roundtrip_rate,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import afsk_oracle as O   # checker + reported CPU baseline only
+        cores = os.cpu_count() or 1
+        ns = args.cpu_sample_streams or min(n_local, 2048)
+        h = samples[: ns * STREAM_LEN].cpu().numpy()
+        h_off = np.arange(ns, dtype=np.int64) * STREAM_LEN
+        h_ln = np.full(ns, STREAM_LEN, np.int32)
+        t1 = time.perf_counter()
+        want1 = O.demod_batch(h[: (ns // 8) * STREAM_LEN], h_off[: ns // 8], h_ln[: ns // 8],
+                              bf_h[: ns // 8], 14000, out_stride=stride, n_threads=1)
+        dt1 = time.perf_counter() - t1
+        reps = 0
+        t2 = time.perf_counter()
+        while True:
+            want = O.demod_batch(h, h_off, h_ln, bf_h[:ns], 14000, out_stride=stride, n_threads=cores)
+            reps += 1
+            if time.perf_counter() - t2 > 10.0 or reps >= 50:
+                break
+        dtc = (time.perf_counter() - t2) / reps
+        match = 0
+        for s in range(ns):
+            nb = int(want["nbytes"][s])
+            same = (nb == int(res.nbytes[s]) and int(want["nbits"][s]) == int(res.nbits[s])
+                    and int(want["clock_idx"][s]) == int(res.clock_idx[s])
+                    and want["bytes"][s, : min(nb, stride)].tobytes() == got_payloads[s][: min(nb, stride)])
+            match += bool(same)
+        del want1
+        out["cpu_baseline"] = {
+            "value": round(ns * STREAM_LEN / dtc / 1e6, 1), "unit": "Msamples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"first {ns} streams of the same batch, CPU oracle (C port of afskmodem.py hot path), "
+                      f"{cores} threads, {reps} reps; single thread on {ns // 8} streams: "
+                      f"{round((ns // 8) * STREAM_LEN / dt1 / 1e6, 1)} Msamples/s",
+            "single_thread_value": round((ns // 8) * STREAM_LEN / dt1 / 1e6, 1),
+        }
+        out["match_rate"] = match / ns
+        out["match_sample_streams"] = ns
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
