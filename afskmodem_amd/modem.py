@@ -298,6 +298,11 @@ class Receiver:
     def __demod_host(self, frames: np.ndarray):
         frames = np.ascontiguousarray(frames, dtype=np.int16)
         self.check_decodable(len(frames))
+        bf = self.__bit_frames
+        if len(frames) < SYNC_WINDOW and (bf % 4 != 0 or 2 * bf >= SYNC_WINDOW):
+            # A baud the kernels reject only ever reaches the reference's early return
+            # (ref:323-325) when the input is too short; mirror that without a launch.
+            return b"", 0, -1, -1, _native.ST_TOO_SHORT
         cap = max(len(frames) // (14 * self.__bit_frames) + 2, 4)
         out_bytes = np.zeros(cap, dtype=np.uint8)
         i32 = [C.c_int32(0) for _ in range(5)]
