@@ -1,483 +1,12 @@
-// afsk_demod.hip -- batched AFSK demodulation for MI355X (gfx950 / CDNA4).
-//
-// One wavefront (64 lanes) owns one stream and runs the whole receiver hot path
-// of lavajuno/afskmodem for it (reference afskmodem.py, "ref:" below):
-//
-//   phase A  clock recovery, ref:322-339   prefix sums of the first 4096 raw
-//            samples in LDS; each sync offset's SAD against the training cycle
-//            is 7 prefix lookups (|hi - x| = 32767 - x and |lo - x| = x + 32768
-//            need no abs for int16 x); first argmin of the truncated means via a
-//            packed (mean << 12 | offset) wave-min.
-//   phase B  symbol decisions, ref:342-351 + limiter ref:287-296 + squelch
-//            amplitude ref:94-98.  The stream is re-read from the clock index as
-//            an LDS-DMA ring (buffer_load_dwordx4 ... lds, 1 KiB per wave
-//            instruction, bounds-checked by the buffer descriptor), so symbol k
-//            sits at LDS byte k*2*bf and every lane reduces one symbol piece with
-//            packed-int16 VALU + v_sad_u16.
-//   phase C  training terminator scan ref:361-366/386-390, squelch stop
-//            ref:372-378, Hamming(7,4) decode ref:145-163 and MSB-first byte pack
-//            ref:393-399 on 64-bit ballot masks (wave-uniform scalar code).
-//
-// No MFMA: this is an HBM-bound streaming reduction (2 B read per sample).
-// No workgroup barrier: the 4 waves of a block are independent streams.
-#include <hip/hip_runtime.h>
-
-#include <stdint.h>
-
-#include "afsk_kernels.h"
+// afsk_demod.hip -- product instantiation of the batched demodulator kernel.
+#include "afsk_demod_impl.h"
 
 namespace afsk {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-
-#define AFSK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
-
-constexpr int kSync = 4096;          // ref:323,327
-constexpr int kWaveLds = 16384;      // bytes of LDS per wave (= 4096 int32 prefix sums)
-constexpr int kWavesPerBlock = 4;
-constexpr uint32_t kBias = 0x80008000u;  // int16 -> order-preserving uint16, packed pair
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-// floor(total / n) for total < 2^27, n < 2^13, exactly (float estimate + fix-up).
-__device__ __forceinline__ uint32_t div_exact(uint32_t total, uint32_t n, float rcp_n) {
-    uint32_t q = (uint32_t)((float)total * rcp_n);
-    int32_t r = (int32_t)(total - q * n);
-    if (r < 0) q -= 1;
-    else if (r >= (int32_t)n) q += 1;
-    return q;
-}
-
-// Limiter ref:287-296 on a packed pair, result biased by 0x8000 per half:
-// x > 512 -> 0xFFFF (32767), x < -512 -> 0x0000 (-32768), else 0x8000 (0).
-__device__ __forceinline__ uint32_t limit_pair_biased(uint32_t x) {
-    const i16x2 xv = __builtin_bit_cast(i16x2, x);
-    const i16x2 k512 = {512, 512};
-    const i16x2 km513 = {-513, -513};
-    i16x2 ps = __builtin_elementwise_sub_sat(k512, xv) >> 15;    // 0xFFFF iff x > 512
-    i16x2 nn = __builtin_elementwise_sub_sat(km513, xv) >> 15;   // 0xFFFF iff x >= -512
-    return (__builtin_bit_cast(uint32_t, nn) & kBias) | __builtin_bit_cast(uint32_t, ps);
-}
-
-// Hamming(7,4) syndrome decode ref:145-151; bit t of cw = received bit t.
-__device__ __forceinline__ uint32_t hamming_nibble(uint32_t cw) {
-    uint32_t s0 = __popc(cw & 0x55u) & 1u;   // parity row 1010101 (ref:126)
-    uint32_t s1 = __popc(cw & 0x66u) & 1u;   // parity row 0110011 (ref:127)
-    uint32_t s2 = __popc(cw & 0x78u) & 1u;   // parity row 0001111 (ref:128)
-    uint32_t pos = s2 * 4u + s1 * 2u + s0;   // ref:147
-    if (pos) cw ^= 1u << (pos - 1u);         // ref:149-150
-    return (((cw >> 2) & 1u) << 3) | (((cw >> 4) & 1u) << 2) | (((cw >> 5) & 1u) << 1) |
-           ((cw >> 6) & 1u);                 // ref:151
-}
-
-// ---------------------------------------------------------------- phase C state
-// Wave-uniform receiver state machine fed 64 symbol decisions at a time.
-struct RxState {
-    int phase;        // 0 = skipping training, 1 = data, 2 = stopped
-    uint32_t hist;    // last three training decisions: bit0 = oldest
-    int32_t nbits;    // coded bits taken (ref:380)
-    int32_t nbytes;   // decoded bytes produced
-    int32_t term_sym; // symbol index after the terminator (ref:368), -1 = none
-    uint32_t pend;    // coded bits not yet forming a byte (< 14 of them)
-    int npend;
-};
-
-// bits / amp_ok: bit j = decision of symbol k0+j (only j < nv meaningful).
-__device__ __forceinline__ void rx_consume(RxState& st, uint64_t bits, uint64_t amp_ok, int nv,
-                                           int k0, int lane, uint8_t* out_row, int out_stride) {
-    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-    bits &= valid;
-    int start = 0;
-    if (st.phase == 0) {
-        // ref:386-390: window (b[k-3], b[k-2], b[k-1], b[k]) == (1,0,0,0)
-        const uint64_t h = st.hist;
-        const uint64_t b3 = (bits << 3) | (h & 7ull);
-        const uint64_t b2 = (bits << 2) | ((h >> 1) & 3ull);
-        const uint64_t b1 = (bits << 1) | ((h >> 2) & 1ull);
-        const uint64_t hit = b3 & ~b2 & ~b1 & ~bits & valid;
-        if (hit) {
-            const int j = __builtin_ctzll(hit);
-            st.term_sym = k0 + j + 1;
-            st.phase = 1;
-            start = j + 1;
-        } else {
-            st.hist = nv >= 3 ? (uint32_t)((bits >> (nv - 3)) & 7ull)
-                              : (uint32_t)(((h | (bits << 3)) >> nv) & 7ull);
-            return;
-        }
-    }
-    if (st.phase != 1 || start >= nv) return;
-    // ref:372-378: take bits until the first symbol whose mean |x| < amp_end
-    const uint64_t from = valid & ~((1ull << start) - 1ull);   // start < 64 here
-    const uint64_t stop = from & ~amp_ok;
-    int end = nv;
-    if (stop) {
-        end = __builtin_ctzll(stop);
-        st.phase = 2;
-    }
-    const int n_new = end - start;
-    if (n_new <= 0) return;
-    uint64_t d = bits >> start;
-    if (n_new < 64) d &= (1ull << n_new) - 1ull;
-    st.nbits += n_new;
-    // append to the pending coded bits; every 14 coded bits = 2 codewords = 1 byte
-    const int np = st.npend;
-    const uint64_t lo = (uint64_t)st.pend | (d << np);
-    const uint64_t hi = np ? (d >> (64 - np)) : 0ull;
-    const int total = np + n_new;       // <= 13 + 64
-    const int nb = total / 14;          // <= 5
-    if (lane < nb) {
-        const int o = 14 * lane;        // <= 56
-        uint32_t c = (uint32_t)(lo >> o);
-        if (o > 50) c |= (uint32_t)(hi << (64 - o));
-        c &= 0x3FFFu;
-        const uint32_t byte = (hamming_nibble(c & 127u) << 4) | hamming_nibble(c >> 7);  // ref:393-399
-        const int pos = st.nbytes + lane;
-        if (pos < out_stride) out_row[pos] = (uint8_t)byte;
-    }
-    st.nbytes += nb;
-    const int used = 14 * nb;           // <= 70
-    const int rem = total - used;       // < 14
-    uint64_t rest;
-    if (used == 0) rest = lo;
-    else if (used < 64) rest = (lo >> used) | (hi << (64 - used));
-    else if (used == 64) rest = hi;
-    else rest = hi >> (used - 64);
-    st.pend = (uint32_t)rest & ((1u << rem) - 1u);
-    st.npend = rem;
-}
-
-// ------------------------------------------------------------------- phase A
-// ref:322-339.  Returns the clock index (wave-uniform).  P = 4096 int32 in LDS.
-__device__ __forceinline__ int recover_clock_index(const int16_t* xs, int32_t len, int bf,
-                                                   int32_t* P, int lane) {
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
-    u32x4 v[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        v[r] = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (512 * r + 8 * lane) * 2, 0, 0));
-    int32_t c[8][8];   // exclusive prefix inside the lane's 8 samples
-    int32_t tot[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int32_t run = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int32_t w = (int32_t)v[r][j];
-            c[r][2 * j] = run;
-            run += (w << 16) >> 16;
-            c[r][2 * j + 1] = run;
-            run += w >> 16;
-        }
-        tot[r] = run;
-    }
-    int32_t incl[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) incl[r] = tot[r];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int32_t t = __shfl_up(incl[r], d, 64);
-            if (lane >= d) incl[r] += t;
-        }
-    }
-    int32_t carry = 0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int32_t base = carry + incl[r] - tot[r];
-        int32_t* dst = P + 512 * r + 8 * lane;
-        u32x4 a = {(uint32_t)(base + c[r][0]), (uint32_t)(base + c[r][1]),
-                   (uint32_t)(base + c[r][2]), (uint32_t)(base + c[r][3])};
-        u32x4 b = {(uint32_t)(base + c[r][4]), (uint32_t)(base + c[r][5]),
-                   (uint32_t)(base + c[r][6]), (uint32_t)(base + c[r][7])};
-        *reinterpret_cast<u32x4*>(dst) = a;
-        *reinterpret_cast<u32x4*>(dst + 4) = b;
-        carry += __shfl(incl[r], 63, 64);
-    }
-    // Same wave wrote and reads P: LDS ops of one wave complete in order.
-    const int q = bf >> 2, h = bf >> 1, n = 2 * bf;
-    const int n_off = kSync - n;                 // ref:327
-    const uint32_t C = 65535u * (uint32_t)bf;    // 32767*bf + 32768*bf
-    const float rcp_n = 1.0f / (float)n;
-    uint32_t best = 0xFFFFFFFFu;
-    for (int i0 = 0; i0 < n_off; i0 += 64) {
-        const int i = i0 + lane;
-        const bool ok = i < n_off;
-        const int ic = ok ? i : n_off - 1;
-        const int32_t* p = P + ic;
-        // training cycle = mark(hi q, lo q, hi q, lo q) + space(hi h, lo h), ref:80-91
-        const int32_t t = p[0] + p[n] +
-                          2 * (p[2 * q] + p[bf] - p[q] - p[3 * q] - p[bf + h]);
-        const uint32_t total = C + (uint32_t)t;                 // sum |tc[j] - x[i+j]|
-        const uint32_t mean = div_exact(total, (uint32_t)n, rcp_n);   // ref:107
-        const uint32_t key = (mean << 12) | (uint32_t)ic;
-        if (ok && key < best) best = key;        // strict <, first minimum: ref:332-337
-    }
-    best = wave_min_u32(best);
-    return (int)(__builtin_amdgcn_readfirstlane(best) & 4095u);
-}
-
-// ------------------------------------------------------------------- phase B
-// Template dwords (biased) for the two samples at symbol phases ph, ph+1.
-__host__ __device__ constexpr uint32_t mark_half(int ph, int q) {
-    return ((ph / q) & 1) ? 0x0000u : 0xFFFFu;   // hi on quarters 0 and 2, ref:80-85
-}
-__host__ __device__ constexpr uint32_t space_half(int ph, int h) {
-    return ph < h ? 0xFFFFu : 0x0000u;           // hi on the first half, ref:68-77
-}
-
-// Specialised symbol loop: BF samples per symbol, M lanes per symbol (each lane a
-// contiguous piece of PL = BF/M samples).  Requires M == 1, or a piece that lies
-// inside one quarter symbol (templates are then one constant per lane).
-template <int BF, int M>
-__device__ __forceinline__ void demod_symbols(const int16_t* xs, int32_t len, int ci,
-                                              int32_t amp_end, uint8_t* lds, int lane,
-                                              RxState& st, uint8_t* out_row, int out_stride,
-                                              int32_t& n_sym_out) {
-    constexpr int PL = BF / M;                   // samples per lane piece
-    constexpr int Q = BF / 4, H = BF / 2;
-    static_assert(BF % 4 == 0 && PL % 2 == 0, "piece must be whole dwords");
-    static_assert(M == 1 || (Q % PL == 0), "piece must lie inside one quarter");
-    constexpr int PIECE_B = PL * 2;              // bytes per lane piece
-    constexpr int PASS_B = 64 * PIECE_B;         // bytes per 64-lane pass
-    constexpr int U = (PASS_B % 1024 == 0) ? 1 : ((2 * PASS_B) % 1024 == 0 ? 2 : 4);
-    constexpr int RB = U * PASS_B;               // bytes per DMA round
-    static_assert(RB % 1024 == 0, "round must be whole 1 KiB DMA instructions");
-    constexpr int NCH = RB / 1024;               // DMA instructions per round
-    constexpr int NSLOT = kWaveLds / RB;         // ring depth
-    static_assert(NSLOT >= 2, "ring needs two slots");
-    constexpr int SPP = 64 / M;                  // symbols per pass
-    constexpr int SPR = SPP * U;                 // symbols per round
-
-    const int32_t rel_len = len - ci;                          // samples from the clock index
-    const int32_t K = (rel_len - BF + BF - 1) / BF;            // symbols with i < len - bf (ref:362,372)
-    n_sym_out = K;
-    const int32_t NR = (K + SPR - 1) / SPR;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + ci), 0, rel_len * 2, 0x00020000);
-    const uint32_t amp_thr =
-        (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
-
-    auto issue_round = [&](int r) {
-        uint8_t* slot = lds + (r % NSLOT) * RB;
-#pragma unroll
-        for (int c = 0; c < NCH; c++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(slot + c * 1024), 16,
-                                                     lane * 16 + c * 1024, r * RB, 0, 0);
-    };
-
-#pragma unroll
-    for (int r = 0; r < NSLOT - 1; r++)
-        if (r < NR) issue_round(r);
-
-    // per-lane constant templates when M > 1
-    const int piece = lane % M;
-    const int quarter = (piece * PL) / Q;
-    const uint32_t tm_lane = (quarter & 1) ? 0u : 0xFFFFFFFFu;
-    const uint32_t ts_lane = quarter < 2 ? 0xFFFFFFFFu : 0u;
-
-    for (int r = 0; r < NR; r++) {
-        if (r + NSLOT - 1 < NR) {
-            issue_round(r + NSLOT - 1);
-            wait_vmcnt<NCH*(NSLOT - 1)>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        const uint8_t* slot = lds + (r % NSLOT) * RB;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int k0 = r * SPR + u * SPP;
-            if (k0 >= K) break;
-            const uint8_t* src = slot + u * PASS_B + lane * PIECE_B;
-            uint32_t w[PL / 2];
-            if constexpr (PIECE_B % 16 == 0) {
-#pragma unroll
-                for (int j = 0; j < PIECE_B / 16; j++) {
-                    u32x4 t = *reinterpret_cast<const u32x4*>(src + 16 * j);
-                    w[4 * j] = t[0]; w[4 * j + 1] = t[1]; w[4 * j + 2] = t[2]; w[4 * j + 3] = t[3];
-                }
-            } else if constexpr (PIECE_B % 8 == 0) {
-#pragma unroll
-                for (int j = 0; j < PIECE_B / 8; j++) {
-                    u32x2 t = *reinterpret_cast<const u32x2*>(src + 8 * j);
-                    w[2 * j] = t[0]; w[2 * j + 1] = t[1];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < PIECE_B / 4; j++)
-                    w[j] = *reinterpret_cast<const uint32_t*>(src + 4 * j);
-            }
-            uint32_t mark = 0, space = 0, amp = 0;
-#pragma unroll
-            for (int d = 0; d < PL / 2; d++) {
-                const uint32_t x = w[d];
-                const uint32_t lim = limit_pair_biased(x);                      // ref:344
-                uint32_t tm, ts;
-                if constexpr (M == 1) {
-                    tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
-                    ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
-                } else {
-                    tm = tm_lane;
-                    ts = ts_lane;
-                }
-                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);                 // ref:346
-                space = __builtin_amdgcn_sad_u16(lim, ts, space);               // ref:347
-                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);          // ref:94-98
-            }
-            if constexpr (M > 1) {
-#pragma unroll
-                for (int s = 1; s < M; s <<= 1) {
-                    mark += (uint32_t)__shfl_xor((int)mark, s, 64);
-                    space += (uint32_t)__shfl_xor((int)space, s, 64);
-                    amp += (uint32_t)__shfl_xor((int)amp, s, 64);
-                }
-            }
-            const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);    // ref:348-351
-            const bool loud = amp >= amp_thr;   // !(int(sum/bf) < amp_end), ref:375
-            uint64_t bmask, amask;
-            if constexpr (M == 1) {
-                bmask = __ballot(bit);
-                amask = __ballot(loud);
-            } else {
-                // lane j < SPP picks up symbol j's decision from lane j*M
-                const int srcl = (lane * M) & 63;
-                const int pk = __shfl((int)bit | ((int)loud << 1), srcl, 64);
-                bmask = __ballot((pk & 1) && lane < SPP);
-                amask = __ballot((pk & 2) && lane < SPP);
-            }
-            const int nv = (K - k0) < SPP ? (K - k0) : SPP;
-            rx_consume(st, bmask, amask, nv, k0, lane, out_row, out_stride);
-            if (st.phase == 2) break;
-        }
-        if (st.phase == 2) break;
-    }
-    wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
-}
-
-// Generic fallback: any bf (multiple of 4, 2*bf < 4096), one lane per symbol,
-// sample-by-sample from LDS.  Correctness path for unusual baud rates.
-__device__ __forceinline__ void demod_symbols_generic(const int16_t* xs, int32_t len, int ci,
-                                                      int bf, int32_t amp_end, uint8_t* lds,
-                                                      int lane, RxState& st, uint8_t* out_row,
-                                                      int out_stride, int32_t& n_sym_out) {
-    const int q = bf >> 2, h = bf >> 1;
-    const int sym_b = bf * 2;
-    int spr = (kWaveLds - 16) / sym_b;
-    if (spr > 64) spr = 64;
-    const int rb = spr * sym_b;
-    const int nch = (rb + 1023) / 1024;
-    const int32_t rel_len = len - ci;
-    const int32_t K = (rel_len - bf + bf - 1) / bf;
-    n_sym_out = K;
-    const int32_t NR = (K + spr - 1) / spr;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + ci), 0, rel_len * 2, 0x00020000);
-    const uint32_t amp_thr =
-        (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)bf;
-    const float rcp_bf = 1.0f / (float)bf;
-    for (int r = 0; r < NR; r++) {
-        for (int c = 0; c < nch; c++) {
-            if (c * 1024 + lane * 16 < rb)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(lds + c * 1024), 16,
-                                                         lane * 16 + c * 1024, r * rb, 0, 0);
-        }
-        wait_vmcnt<0>();
-        const int16_t* src = reinterpret_cast<const int16_t*>(lds + (lane < spr ? lane : 0) * sym_b);
-        uint32_t mark = 0, space = 0, amp = 0;
-        for (int j = 0; j < bf; j++) {
-            const int32_t x = src[j];
-            const int32_t a = x > 512 ? 32767 : (x < -512 ? -32768 : 0);       // ref:287-296
-            const int32_t tm = ((j / q) & 1) ? -32768 : 32767;
-            const int32_t ts = j < h ? 32767 : -32768;
-            mark += (uint32_t)(tm > a ? tm - a : a - tm);
-            space += (uint32_t)(ts > a ? ts - a : a - ts);
-            amp += (uint32_t)(x < 0 ? -x : x);
-        }
-        const bool bit = div_exact(mark, (uint32_t)bf, rcp_bf) < div_exact(space, (uint32_t)bf, rcp_bf);
-        const bool loud = amp >= amp_thr;
-        const uint64_t bmask = __ballot(bit && lane < spr);
-        const uint64_t amask = __ballot(loud && lane < spr);
-        const int k0 = r * spr;
-        const int nv = (K - k0) < spr ? (K - k0) : spr;
-        // all lanes must have finished reading before the next round overwrites the slot
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        rx_consume(st, bmask, amask, nv, k0, lane, out_row, out_stride);
-        if (st.phase == 2) break;
-    }
-    wait_vmcnt<0>();
-}
-
-__global__ __launch_bounds__(64 * kWavesPerBlock) void demod_kernel(DemodArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kWaveLds];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = blockIdx.x * kWavesPerBlock + wave;
-    if (s >= a.n_streams) return;
-    uint8_t* lds = lds_all + wave * kWaveLds;
-
-    const int64_t off = a.stream_offset[s];
-    const int32_t len = a.stream_len[s];
-    const int bf = a.bit_frames[s];
-    const int16_t* xs = a.samples + off;
-    uint8_t* out_row = a.out_bytes + (int64_t)s * a.out_stride;
-
-    if (bf < 4 || (bf & 3) || 2 * bf >= kSync) {   // host validates first; stay memory-safe anyway
-        if (lane == 0) {
-            a.out_nbytes[s] = 0; a.out_nbits[s] = 0; a.out_clock_idx[s] = -1;
-            a.out_term_frame[s] = -1; a.out_status[s] = 3;
-        }
-        return;
-    }
-    if (len < kSync) {   // ref:323-325
-        if (lane == 0) {
-            a.out_nbytes[s] = 0; a.out_nbits[s] = 0; a.out_clock_idx[s] = -1;
-            a.out_term_frame[s] = -1; a.out_status[s] = 1;
-        }
-        return;
-    }
-    const int ci = recover_clock_index(xs, len, bf, reinterpret_cast<int32_t*>(lds), lane);
-    // phase B reuses the prefix-sum region: all LDS reads of phase A have returned
-    // (their values were consumed), so the DMA writes below cannot overtake them.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-    RxState st;
-    st.phase = 0; st.hist = 0; st.nbits = 0; st.nbytes = 0; st.term_sym = -1; st.pend = 0;
-    st.npend = 0;
-    int32_t n_sym = 0;
-    switch (bf) {
-        case 40:  demod_symbols<40, 1>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-        case 20:  demod_symbols<20, 1>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-        case 160: demod_symbols<160, 4>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-        default:  demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-    }
-    if (lane == 0) {
-        const int32_t term_sym = st.term_sym >= 0 ? st.term_sym : n_sym;   // ref:362-368
-        a.out_nbytes[s] = st.nbytes;
-        a.out_nbits[s] = st.nbits;
-        a.out_clock_idx[s] = ci;
-        a.out_term_frame[s] = ci + term_sym * bf;
-        a.out_status[s] = st.nbits == 0 ? 2 : 0;   // ref:422-424
-    }
-}
 
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream) {
     if (a.n_streams <= 0) return hipSuccess;
     const int blocks = (a.n_streams + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(demod_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+    hipLaunchKernelGGL((demod_kernel_t<0, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
     return hipGetLastError();
 }
 

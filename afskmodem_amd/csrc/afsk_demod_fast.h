@@ -1,0 +1,313 @@
+// afsk_demod_fast.h -- stream-aligned single-pass path for the common baud rates
+// (bit_frames 20 / 40 / 160 = 2400 / 1200 / 300 baud).  Included by afsk_demod_impl.h.
+//
+// Every sample is fetched from HBM exactly once: the wave starts a 16 KiB LDS-DMA
+// ring at sample 0 the moment it starts, BEFORE the clock index is known, so the
+// memory pipe is busy while phase A computes.
+//
+//   ring      16 x 1 KiB chunks; chunk c (samples 512c .. 512c+511) lives in slot
+//             c & 15; one `buffer_load_dwordx4 ... lds` per chunk, bounds-checked by
+//             a descriptor over the whole stream (tail reads return 0).
+//   phase A   ref:322-339 on the first 8 chunks as they land (progressive vmcnt):
+//             a producer turns 128 raw samples per step into exclusive prefix sums
+//             (DPP wave scan) kept in a 512-entry circular window; the consumer
+//             evaluates 64 sync offsets per step with 7 window reads each.
+//   phase B   ref:342-351: every lane owns an 80-byte piece (40 samples: one
+//             1200-baud symbol, two 2400-baud symbols, a quarter 300-baud symbol) at
+//             ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as six aligned
+//             ds_read_b128 and re-aligned in registers by the wave-uniform shift
+//             (2*ci) & 15 (v_alignbyte).  After the reads of round r the five chunks
+//             it consumed are refilled immediately (11 KiB stay in flight).
+#pragma once
+#include <type_traits>
+
+namespace afsk {
+
+constexpr int kRingBytes = 16384;
+constexpr int kRingChunks = 16;
+
+__device__ __forceinline__ void wait_vmcnt_sw(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break; default: wait_vmcnt<15>(); break;
+    }
+}
+
+// Inclusive wave scan (64 lanes) with DPP: 4 row_shr steps + row_bcast:15 + row_bcast:31.
+__device__ __forceinline__ int32_t wave_incl_scan_dpp(int32_t v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+struct FastRing {
+    __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
+    uint8_t* ring;                 // wave-uniform LDS base of the 16 KiB ring
+    int lane;
+    int next;                      // next chunk id to issue
+
+    __device__ __forceinline__ void issue(int c) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + (c & (kRingChunks - 1)) * 1024),
+                                                 16, lane * 16, c * 1024, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------ phase A (fast)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Geometry of the circular prefix-sum window for one baud rate.  The window holds PW
+// entries; its first MIRROR entries are stored a second time at [PW, PW + MIRROR) so that a
+// consumer can read P[i + e] at (i mod PW) + e without wrapping: every LDS address of the
+// search is then `lane*4 + immediate`.
+template <int BF>
+struct SyncGeom {
+    static constexpr int N = 2 * BF;
+    static constexpr int PW = (N + 192 <= 256) ? 256 : 512;
+    static constexpr int MIRROR = ((N + 64 + 127) / 128) * 128;
+    static constexpr int ENTRIES = PW + MIRROR;
+    static_assert(N + 192 <= PW, "prefix window too small for this baud");
+};
+constexpr int kPWinMaxBytes = SyncGeom<160>::ENTRIES * 4;      // 3.5 KiB (largest of 20/40/160)
+constexpr int kFastWaveLds = kRingBytes + kPWinMaxBytes;
+
+template <int BF, bool DEBUG = false>
+__device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
+                                                        uint32_t* dbg = nullptr) {
+    using G = SyncGeom<BF>;
+    constexpr int N = G::N, Q = BF / 4, H = BF / 2, PW = G::PW;
+    constexpr int NOFF = kSync - N;                       // ref:327
+    constexpr int T = (NOFF + 63) / 64;                   // consumer steps of 64 offsets
+    constexpr uint32_t C = 65535u * (uint32_t)BF;
+    // floor(total / N) for total < 2^27 as mul_hi(total, M) >> 4 with M = ceil(2^36 / N):
+    // error term total * (M*N - 2^36) < 2^27 * N <= 2^36 for N <= 512.
+    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
+    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
+    const int lane = fr.lane;
+    const uint32_t* raw = reinterpret_cast<const uint32_t*>(fr.ring);
+    int32_t carry = 0;
+    uint32_t best = 0xFFFFFFFFu;
+    // producer steps (128 samples each) that must be complete before consumer step t
+    auto done_before = [](int t) constexpr { return t < 0 ? 0 : ((64 * t + 63 + N) / 128 + 1 > 32 ? 32 : (64 * t + 63 + N) / 128 + 1); };
+    static_for<0, T>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int u0 = done_before(t - 1), u1 = done_before(t);
+        static_for<u0, u1>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr ((u & 3) == 0) wait_vmcnt<15 - u / 4>();        // chunk u/4 has landed
+            const uint32_t w = raw[64 * u + lane];
+            const int32_t x0 = ((int32_t)(w << 16)) >> 16, x1 = ((int32_t)w) >> 16;
+            const int32_t s = x0 + x1;
+            const int32_t incl = wave_incl_scan_dpp(s);
+            const int32_t base = carry + incl - s;
+            constexpr int j0 = (128 * u) & (PW - 1);
+            int32_t* dst = pw + j0 + 2 * lane;
+            dst[0] = base;                                // P[128u + 2*lane]
+            dst[1] = base + x0;                           // P[128u + 2*lane + 1]
+            if constexpr (j0 < G::MIRROR) {
+                dst[PW] = base;
+                dst[PW + 1] = base + x0;
+            }
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        });
+        if constexpr (u1 > u0) wave_lds_sync();           // other lanes read these stores
+        // consumer: total(i) = sum_j |tc[j] - x[i+j]| for i = 64t + lane (see afsk_demod_impl.h)
+        constexpr int b0 = (64 * t) & (PW - 1);
+        const int32_t* p = pw + b0 + lane;
+        const int32_t tt = p[0] + p[N] + 2 * (p[2 * Q] + p[BF] - p[Q] - p[3 * Q] - p[BF + H]);
+        const uint32_t total = C + (uint32_t)tt;
+        const uint32_t mean = __umulhi(total, M) >> 4;    // ref:107, exact integer division
+        const uint32_t key = (mean << 12) | (uint32_t)(64 * t + lane);
+        if constexpr (DEBUG) dbg[64 * t + lane] = total;
+        if constexpr (64 * t + 63 < NOFF) {
+            best = key < best ? key : best;               // strict <, first minimum: ref:332-337
+        } else {
+            if (64 * t + lane < NOFF && key < best) best = key;
+        }
+    });
+    best = wave_min_u32(best);
+    return (int)(__builtin_amdgcn_readfirstlane(best) & 4095u);
+}
+
+// ------------------------------------------------------------------ phase B (fast)
+// Re-align 24 dwords (six aligned 16-byte reads) by S bytes into 20 dwords.
+template <int S>
+__device__ __forceinline__ void realign(const uint32_t (&W)[24], uint32_t (&x)[20]) {
+    constexpr int A = S / 4, B = S % 4;
+#pragma unroll
+    for (int d = 0; d < 20; d++) {
+        if constexpr (B == 0) x[d] = W[d + A];
+        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
+    }
+}
+
+template <int BF, int FLAGS>
+__device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int lane, uint32_t amp_thr,
+                                                   int32_t K, int k0, RxState& st, uint8_t* out_row,
+                                                   int out_stride) {
+    constexpr int Q = BF / 4, H = BF / 2;
+    if constexpr (BF == 40) {                 // one symbol per lane
+        uint32_t mark = 0, space = 0, amp = 0;
+        if constexpr (FLAGS & 2) {
+#pragma unroll
+            for (int d = 0; d < 20; d++) amp |= x[d];
+            mark = amp & 1; space = 1; amp = 0x7fffffff;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 20; d++) {
+                const uint32_t lim = limit_pair_biased(x[d]);
+                const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
+                const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
+                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
+                space = __builtin_amdgcn_sad_u16(lim, ts, space);
+                amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
+            }
+        }
+        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);
+        const bool loud = amp >= amp_thr;
+        const int nv = (K - k0) < 64 ? (K - k0) : 64;
+        rx_consume(st, __ballot(bit), __ballot(loud), nv, k0, lane, out_row, out_stride);
+    } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 and 10-19
+        uint32_t mk[2] = {0, 0}, sp[2] = {0, 0}, am[2] = {0, 0};
+#pragma unroll
+        for (int d = 0; d < 20; d++) {
+            const int h2 = d / 10, dd = d % 10;
+            const uint32_t lim = limit_pair_biased(x[d]);
+            const uint32_t tm = mark_half(2 * dd, Q) | (mark_half(2 * dd + 1, Q) << 16);
+            const uint32_t ts = space_half(2 * dd, H) | (space_half(2 * dd + 1, H) << 16);
+            mk[h2] = __builtin_amdgcn_sad_u16(lim, tm, mk[h2]);
+            sp[h2] = __builtin_amdgcn_sad_u16(lim, ts, sp[h2]);
+            am[h2] = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, am[h2]);
+        }
+        int pk = 0;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const bool bit = (mk[h2] / (uint32_t)BF) < (sp[h2] / (uint32_t)BF);
+            const bool loud = am[h2] >= amp_thr;
+            pk |= ((int)bit | ((int)loud << 1)) << (2 * h2);
+        }
+        // symbol j of this round lives in lane j/2, half j%2: two passes of 64 symbols
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int kk = k0 + 64 * half;
+            if (kk >= K || st.phase == 2) break;
+            const int v = __shfl(pk, 32 * half + (lane >> 1), 64) >> (2 * (lane & 1));
+            const int nv = (K - kk) < 64 ? (K - kk) : 64;
+            rx_consume(st, __ballot(v & 1), __ballot(v & 2), nv, kk, lane, out_row, out_stride);
+        }
+    } else {                                  // BF == 160: four lanes per symbol, one quarter each
+        static_assert(BF == 160, "fast path supports bit_frames 20, 40, 160");
+        const int quarter = lane & 3;
+        const uint32_t tm = (quarter & 1) ? 0u : 0xFFFFFFFFu;
+        const uint32_t ts = quarter < 2 ? 0xFFFFFFFFu : 0u;
+        uint32_t mark = 0, space = 0, amp = 0;
+#pragma unroll
+        for (int d = 0; d < 20; d++) {
+            const uint32_t lim = limit_pair_biased(x[d]);
+            mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
+            space = __builtin_amdgcn_sad_u16(lim, ts, space);
+            amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
+        }
+#pragma unroll
+        for (int s = 1; s < 4; s <<= 1) {
+            mark += (uint32_t)__shfl_xor((int)mark, s, 64);
+            space += (uint32_t)__shfl_xor((int)space, s, 64);
+            amp += (uint32_t)__shfl_xor((int)amp, s, 64);
+        }
+        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);
+        const bool loud = amp >= amp_thr;
+        const int pk = __shfl((int)bit | ((int)loud << 1), (lane * 4) & 63, 64);
+        const int nv = (K - k0) < 16 ? (K - k0) : 16;
+        rx_consume(st, __ballot((pk & 1) && lane < 16), __ballot((pk & 2) && lane < 16), nv, k0,
+                   lane, out_row, out_stride);
+    }
+}
+
+template <int BF, int FLAGS>
+__device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
+                                                  uint8_t* lds, int lane, RxState& st,
+                                                  uint8_t* out_row, int out_stride, int& ci_out,
+                                                  int32_t& n_sym_out) {
+    constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
+    FastRing fr;
+    fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
+    fr.ring = lds;
+    fr.lane = lane;
+#pragma unroll
+    for (int c = 0; c < kRingChunks; c++) fr.issue(c);
+    fr.next = kRingChunks;
+
+    int ci = 0;
+    if constexpr (FLAGS & 1) {
+        wait_vmcnt<8>();
+    } else {
+        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kRingBytes));
+    }
+    ci_out = ci;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    const int32_t rel_len = len - ci;
+    const int32_t K = (rel_len - 1) / BF;                      // symbols with i < len - bf (ref:362,372)
+    n_sym_out = K;
+    const int32_t NR = (K + SPR - 1) / SPR;
+    const uint32_t amp_thr =
+        (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
+    const int byte0 = 2 * ci;                                  // ring byte of symbol 0
+    const int shift = byte0 & 15;                              // wave-uniform re-alignment
+    // chunks entirely below the clock index are free already
+    {
+        const int lim = (byte0 >> 10) + kRingChunks;
+        while (fr.next < lim) { fr.issue(fr.next); fr.next++; }
+    }
+    for (int r = 0; r < NR; r++) {
+        // bytes [byte0 + 5120 r, byte0 + 5120 (r+1) + 16) must have landed: at most 6 chunks
+        // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
+        // 10 youngest DMAs may still be in flight.
+        wait_vmcnt<10>();
+        const int pb = byte0 + 5120 * r + 80 * lane;
+        const int ab = pb & ~15;
+        uint32_t W[24];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((ab + 16 * j) & (kRingBytes - 1)));
+            W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+        }
+        uint32_t x[20];
+        switch (shift) {
+            case 0: realign<0>(W, x); break;
+            case 2: realign<2>(W, x); break;
+            case 4: realign<4>(W, x); break;
+            case 6: realign<6>(W, x); break;
+            case 8: realign<8>(W, x); break;
+            case 10: realign<10>(W, x); break;
+            case 12: realign<12>(W, x); break;
+            default: realign<14>(W, x); break;
+        }
+        // the reads above have returned (their values are in x): refill the 5 chunks this
+        // round consumed right away, before the arithmetic
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 5; j++) fr.issue(fr.next + j);
+        fr.next += 5;
+        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, st, out_row, out_stride);
+        if (st.phase == 2) break;
+    }
+    wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
+}
+
+}  // namespace afsk

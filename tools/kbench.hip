@@ -1,0 +1,99 @@
+// kbench.hip -- interleaved A/B timing of demod kernel variants in ONE process
+// (cdna_hip_programming.md rule 24).  Diagnostic tool, not part of the product.
+//   ./kbench [n_streams=4096] [baud=1200] [rounds=15] [reps=5]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../afskmodem_amd/csrc/afsk_demod_impl.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+using afsk::DemodArgs;
+typedef void (*launch_fn)(const DemodArgs&, hipStream_t);
+
+template <int FLAGS, bool FAST>
+static void launch_flags(const DemodArgs& a, hipStream_t s) {
+    const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
+    hipLaunchKernelGGL((afsk::demod_kernel_t<FLAGS, FAST>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
+}
+
+struct Variant { const char* name; launch_fn fn; bool exact; };
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 4096;
+    const int baud = argc > 2 ? atoi(argv[2]) : 1200;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 15;
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;
+    const int L = 48000, bfv = 48000 / baud;
+    const int plen_v = baud == 1200 ? 34 : (baud == 300 ? 8 : 68);
+    std::vector<int64_t> off(n); std::vector<int32_t> len(n, L), bf(n, bfv), pl(n, plen_v), ts(n, baud / 4);
+    std::vector<uint8_t> payload((size_t)n * plen_v);
+    for (size_t i = 0; i < payload.size(); i++) payload[i] = (uint8_t)((i * 2654435761u) >> 13);
+    for (int i = 0; i < n; i++) off[i] = (int64_t)i * L;
+    int16_t* d_x; int64_t* d_off; int32_t *d_len, *d_bf, *d_pl, *d_ts; uint8_t* d_payload;
+    CK(hipMalloc(&d_x, (size_t)n * L * 2)); CK(hipMalloc(&d_off, n * 8)); CK(hipMalloc(&d_len, n * 4));
+    CK(hipMalloc(&d_bf, n * 4)); CK(hipMalloc(&d_pl, n * 4)); CK(hipMalloc(&d_ts, n * 4));
+    CK(hipMalloc(&d_payload, payload.size()));
+    CK(hipMemcpy(d_off, off.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_len, len.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_bf, bf.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pl, pl.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_ts, ts.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_payload, payload.data(), payload.size(), hipMemcpyHostToDevice));
+    afsk::ModulateArgs m{d_payload, plen_v, d_pl, d_bf, d_ts, d_off, d_len, n, 1, d_x, 0};
+    CK(afsk::launch_modulate(m, L, 0));
+    CK(hipDeviceSynchronize());
+
+    const int stride = 72;
+    uint8_t* d_ob; int32_t* d_i32;
+    CK(hipMalloc(&d_ob, (size_t)n * stride)); CK(hipMalloc(&d_i32, (size_t)n * 5 * 4));
+    DemodArgs a{d_x, d_off, d_len, d_bf, 14000, n, d_ob, stride, d_i32, d_i32 + n, d_i32 + 2 * n, d_i32 + 3 * n, d_i32 + 4 * n};
+
+    std::vector<Variant> vs = {
+        {"v1 two-pass", launch_flags<0, false>, true},
+        {"v2 fast", launch_flags<0, true>, true},
+        {"v1 skip_sync", launch_flags<1, false>, true},
+        {"v2 skip_sync", launch_flags<1, true>, true},
+        {"v1 skip_sync+valu", launch_flags<3, false>, false},
+        {"v2 skip_sync+valu", launch_flags<3, true>, false},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> times(vs.size());
+    // reference outputs from variant 0
+    std::vector<uint8_t> ref_ob((size_t)n * stride), ob((size_t)n * stride);
+    std::vector<int32_t> ref_i((size_t)n * 5), iv((size_t)n * 5);
+    for (size_t v = 0; v < vs.size(); v++) {
+        CK(hipMemset(d_ob, 0, (size_t)n * stride)); CK(hipMemset(d_i32, 0xff, (size_t)n * 20));
+        vs[v].fn(a, 0); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ob.data(), d_ob, ob.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(iv.data(), d_i32, iv.size() * 4, hipMemcpyDeviceToHost));
+        if (v == 0) { ref_ob = ob; ref_i = iv;
+            long okb = 0; for (int s = 0; s < n; s++) okb += iv[s] == plen_v && !memcmp(&ob[(size_t)s * stride], &payload[(size_t)s * plen_v], plen_v);
+            printf("base: %ld / %d streams decode to their payload\n", okb, n);
+        } else if (vs[v].exact) {
+            printf("%s: outputs %s base\n", vs[v].name, (ob == ref_ob && iv == ref_i) ? "==" : "!=");
+        }
+    }
+    for (int r = 0; r < rounds; r++)
+        for (size_t v = 0; v < vs.size(); v++) {
+            CK(hipEventRecord(e0, 0));
+            for (int k = 0; k < reps; k++) vs[v].fn(a, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) times[v].push_back(ms / reps);
+        }
+    const double bytes = 2.0 * n * L;
+    printf("n=%d baud=%d  (full-buffer bytes %.1f MB)\n", n, baud, bytes / 1e6);
+    for (size_t v = 0; v < vs.size(); v++) {
+        std::sort(times[v].begin(), times[v].end());
+        float med = times[v][times[v].size() / 2], mn = times[v][0];
+        printf("%-18s median %8.2f us  min %8.2f us   full-buffer %.2f TB/s (median)\n", vs[v].name, med * 1e3, mn * 1e3, bytes / (med * 1e-3) / 1e12);
+    }
+    return 0;
+}
