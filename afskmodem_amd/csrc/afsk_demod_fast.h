@@ -56,9 +56,10 @@ struct FastRing {
     int lane;
     int next;                      // next chunk id to issue
 
+    template <int AUX = 0>
     __device__ __forceinline__ void issue(int c) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + (c & (kRingChunks - 1)) * 1024),
-                                                 16, lane * 16, c * 1024, 0, 0);
+                                                 16, lane * 16, c * 1024, 0, AUX);
     }
 };
 
@@ -156,34 +157,59 @@ __device__ __forceinline__ void realign(const uint32_t (&W)[24], uint32_t (&x)[2
     }
 }
 
+// Sum over the dwords [D0, D1) of |0xFFFF - limited(x)| per 16-bit half: the SAD of the
+// limited samples against a "hi" (32767) template.  Against a "lo" (-32768) template the
+// SAD of the same samples is 65535 * n_samples minus this, so one v_sad_u16 per dword
+// serves both the mark and the space correlator (ref:346-347).
+template <int D0, int D1>
+__device__ __forceinline__ uint32_t hi_sad(const uint32_t (&x)[20]) {
+    uint32_t h = 0;
+#pragma unroll
+    for (int d = D0; d < D1; d++) h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, h);
+    return h;
+}
+
+template <int D0, int D1>
+__device__ __forceinline__ uint32_t abs_sum(const uint32_t (&x)[20]) {   // ref:94-98
+    uint32_t a = 0;
+#pragma unroll
+    for (int d = D0; d < D1; d++) a = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, a);
+    return a;
+}
+
+// One 5 KiB round: symbol decisions, then (only once the training terminator has been
+// seen) squelch amplitudes, Hamming decode and byte pack.
 template <int BF, int FLAGS>
 __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int lane, uint32_t amp_thr,
                                                    int32_t K, int k0, RxState& st, uint8_t* out_row,
                                                    int out_stride) {
     constexpr int Q = BF / 4, H = BF / 2;
-    if constexpr (BF == 40) {                 // one symbol per lane
-        uint32_t mark = 0, space = 0, amp = 0;
+    constexpr uint32_t FULL = 65535u;
+    if constexpr (BF == 40) {                 // one symbol per lane, 5 dwords per quarter
+        uint32_t mark, space;
         if constexpr (FLAGS & 2) {
+            uint32_t o = 0;
 #pragma unroll
-            for (int d = 0; d < 20; d++) amp |= x[d];
-            mark = amp & 1; space = 1; amp = 0x7fffffff;
+            for (int d = 0; d < 20; d++) o |= x[d];
+            mark = o & 1; space = 1;
         } else {
-#pragma unroll
-            for (int d = 0; d < 20; d++) {
-                const uint32_t lim = limit_pair_biased(x[d]);
-                const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
-                const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
-                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
-                space = __builtin_amdgcn_sad_u16(lim, ts, space);
-                amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
-            }
+            const uint32_t h0 = hi_sad<0, 5>(x), h1 = hi_sad<5, 10>(x), h2 = hi_sad<10, 15>(x),
+                           h3 = hi_sad<15, 20>(x);
+            // mark = hi,lo,hi,lo quarters (ref:80-85); space = hi,hi,lo,lo (ref:68-77)
+            mark = 2u * FULL * Q + h0 + h2 - h1 - h3;
+            space = 2u * FULL * Q + h0 + h1 - h2 - h3;
         }
-        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);
-        const bool loud = amp >= amp_thr;
+        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);     // ref:348-351
         const int nv = (K - k0) < 64 ? (K - k0) : 64;
-        rx_consume(st, __ballot(bit), __ballot(loud), nv, k0, lane, out_row, out_stride);
+        const uint64_t bmask = __ballot(bit);
+        const int start = rx_training(st, bmask, nv, k0);
+        if (start >= 0 && start < nv) {
+            uint32_t amp = 0x7fffffffu;
+            if constexpr (!(FLAGS & 2)) amp = abs_sum<0, 20>(x);
+            rx_data(st, bmask, __ballot(amp >= amp_thr), start, nv, lane, out_row, out_stride);
+        }
     } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 and 10-19
-        uint32_t mk[2] = {0, 0}, sp[2] = {0, 0}, am[2] = {0, 0};
+        uint32_t mk[2] = {0, 0}, sp[2] = {0, 0};
 #pragma unroll
         for (int d = 0; d < 20; d++) {
             const int h2 = d / 10, dd = d % 10;
@@ -192,49 +218,112 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             const uint32_t ts = space_half(2 * dd, H) | (space_half(2 * dd + 1, H) << 16);
             mk[h2] = __builtin_amdgcn_sad_u16(lim, tm, mk[h2]);
             sp[h2] = __builtin_amdgcn_sad_u16(lim, ts, sp[h2]);
-            am[h2] = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, am[h2]);
         }
-        int pk = 0;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            const bool bit = (mk[h2] / (uint32_t)BF) < (sp[h2] / (uint32_t)BF);
-            const bool loud = am[h2] >= amp_thr;
-            pk |= ((int)bit | ((int)loud << 1)) << (2 * h2);
-        }
+        const int pkb = (int)((mk[0] / (uint32_t)BF) < (sp[0] / (uint32_t)BF)) |
+                        ((int)((mk[1] / (uint32_t)BF) < (sp[1] / (uint32_t)BF)) << 1);
+        int pka = -1;                          // amplitudes computed lazily, once per round
         // symbol j of this round lives in lane j/2, half j%2: two passes of 64 symbols
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int kk = k0 + 64 * half;
             if (kk >= K || st.phase == 2) break;
-            const int v = __shfl(pk, 32 * half + (lane >> 1), 64) >> (2 * (lane & 1));
             const int nv = (K - kk) < 64 ? (K - kk) : 64;
-            rx_consume(st, __ballot(v & 1), __ballot(v & 2), nv, kk, lane, out_row, out_stride);
+            const int vb = __shfl(pkb, 32 * half + (lane >> 1), 64) >> (lane & 1);
+            const uint64_t bmask = __ballot(vb & 1);
+            const int start = rx_training(st, bmask, nv, kk);
+            if (start >= 0 && start < nv) {
+                if (pka < 0)
+                    pka = (int)(abs_sum<0, 10>(x) >= amp_thr) | ((int)(abs_sum<10, 20>(x) >= amp_thr) << 1);
+                const int va = __shfl(pka, 32 * half + (lane >> 1), 64) >> (lane & 1);
+                rx_data(st, bmask, __ballot(va & 1), start, nv, lane, out_row, out_stride);
+            }
         }
     } else {                                  // BF == 160: four lanes per symbol, one quarter each
         static_assert(BF == 160, "fast path supports bit_frames 20, 40, 160");
         const int quarter = lane & 3;
-        const uint32_t tm = (quarter & 1) ? 0u : 0xFFFFFFFFu;
-        const uint32_t ts = quarter < 2 ? 0xFFFFFFFFu : 0u;
-        uint32_t mark = 0, space = 0, amp = 0;
-#pragma unroll
-        for (int d = 0; d < 20; d++) {
-            const uint32_t lim = limit_pair_biased(x[d]);
-            mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
-            space = __builtin_amdgcn_sad_u16(lim, ts, space);
-            amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
-        }
+        const uint32_t h = hi_sad<0, 20>(x);
+        const uint32_t l = FULL * Q - h;                          // SAD of this quarter vs a lo template
+        uint32_t mark = (quarter & 1) ? l : h;
+        uint32_t space = quarter < 2 ? h : l;
 #pragma unroll
         for (int s = 1; s < 4; s <<= 1) {
             mark += (uint32_t)__shfl_xor((int)mark, s, 64);
             space += (uint32_t)__shfl_xor((int)space, s, 64);
-            amp += (uint32_t)__shfl_xor((int)amp, s, 64);
         }
         const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);
-        const bool loud = amp >= amp_thr;
-        const int pk = __shfl((int)bit | ((int)loud << 1), (lane * 4) & 63, 64);
+        const int srcl = (lane * 4) & 63;                          // lane j < 16 <- symbol j
         const int nv = (K - k0) < 16 ? (K - k0) : 16;
-        rx_consume(st, __ballot((pk & 1) && lane < 16), __ballot((pk & 2) && lane < 16), nv, k0,
-                   lane, out_row, out_stride);
+        const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < 16);
+        const int start = rx_training(st, bmask, nv, k0);
+        if (start >= 0 && start < nv) {
+            uint32_t amp = abs_sum<0, 20>(x);
+#pragma unroll
+            for (int s = 1; s < 4; s <<= 1) amp += (uint32_t)__shfl_xor((int)amp, s, 64);
+            const uint64_t amask = __ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < 16);
+            rx_data(st, bmask, amask, start, nv, lane, out_row, out_stride);
+        }
+    }
+}
+
+// The round loop.  ALIGNED = the wave-uniform shift (2*ci) & 15 is zero (always true for
+// Transmitter-generated streams, whose clock index is a multiple of the training period):
+// five aligned ds_read_b128 feed the arithmetic directly.  Otherwise six reads + v_alignbyte.
+template <int BF, int FLAGS, bool ALIGNED>
+__device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
+                                            uint32_t amp_thr, RxState& st, uint8_t* out_row,
+                                            int out_stride) {
+    constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
+    const int lane = fr.lane;
+    const int shift = byte0 & 15;
+    for (int r = 0; r < NR; r++) {
+        // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
+        // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
+        // 10 youngest DMAs may still be in flight.
+        wait_vmcnt<10>();
+        uint32_t x[20];
+        const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
+        if constexpr (ALIGNED) {
+            if (rb + 5120 <= kRingBytes) {                              // no wrap in this round
+                const uint8_t* src = fr.ring + rb + 80 * lane;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
+                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+                }
+            } else {
+                const int pb = rb + 80 * lane;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((pb + 16 * j) & (kRingBytes - 1)));
+                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+                }
+            }
+        } else {
+            const int ab = (rb + 80 * lane) & ~15;
+            uint32_t W[24];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((ab + 16 * j) & (kRingBytes - 1)));
+                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+            }
+            switch (shift) {
+                case 2: realign<2>(W, x); break;
+                case 4: realign<4>(W, x); break;
+                case 6: realign<6>(W, x); break;
+                case 8: realign<8>(W, x); break;
+                case 10: realign<10>(W, x); break;
+                case 12: realign<12>(W, x); break;
+                default: realign<14>(W, x); break;
+            }
+        }
+        // the reads above have returned (their values are in x): refill the 5 chunks this
+        // round consumed right away, before the arithmetic
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+        fr.next += 5;
+        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, st, out_row, out_stride);
+        if (st.phase == 2) break;
     }
 }
 
@@ -249,7 +338,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     fr.ring = lds;
     fr.lane = lane;
 #pragma unroll
-    for (int c = 0; c < kRingChunks; c++) fr.issue(c);
+    for (int c = 0; c < kRingChunks; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
     fr.next = kRingChunks;
 
     int ci = 0;
@@ -268,45 +357,13 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
     const int byte0 = 2 * ci;                                  // ring byte of symbol 0
-    const int shift = byte0 & 15;                              // wave-uniform re-alignment
     // chunks entirely below the clock index are free already
     {
         const int lim = (byte0 >> 10) + kRingChunks;
-        while (fr.next < lim) { fr.issue(fr.next); fr.next++; }
+        while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
     }
-    for (int r = 0; r < NR; r++) {
-        // bytes [byte0 + 5120 r, byte0 + 5120 (r+1) + 16) must have landed: at most 6 chunks
-        // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
-        // 10 youngest DMAs may still be in flight.
-        wait_vmcnt<10>();
-        const int pb = byte0 + 5120 * r + 80 * lane;
-        const int ab = pb & ~15;
-        uint32_t W[24];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((ab + 16 * j) & (kRingBytes - 1)));
-            W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
-        }
-        uint32_t x[20];
-        switch (shift) {
-            case 0: realign<0>(W, x); break;
-            case 2: realign<2>(W, x); break;
-            case 4: realign<4>(W, x); break;
-            case 6: realign<6>(W, x); break;
-            case 8: realign<8>(W, x); break;
-            case 10: realign<10>(W, x); break;
-            case 12: realign<12>(W, x); break;
-            default: realign<14>(W, x); break;
-        }
-        // the reads above have returned (their values are in x): refill the 5 chunks this
-        // round consumed right away, before the arithmetic
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 5; j++) fr.issue(fr.next + j);
-        fr.next += 5;
-        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, st, out_row, out_stride);
-        if (st.phase == 2) break;
-    }
+    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, st, out_row, out_stride);
+    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, st, out_row, out_stride);
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 

@@ -109,32 +109,38 @@ struct RxState {
     int npend;
 };
 
-// bits / amp_ok: bit j = decision of symbol k0+j (only j < nv meaningful).
-__device__ __forceinline__ void rx_consume(RxState& st, uint64_t bits, uint64_t amp_ok, int nv,
-                                           int k0, int lane, uint8_t* out_row, int out_stride) {
+// Training part (ref:361-366, 386-390).  bits: bit j = decision of symbol k0+j (j < nv).
+// Returns the index of the first DATA symbol inside this pass (0..nv; nv = none of them),
+// or -1 while the terminator has not been seen / after the squelch stop.
+__device__ __forceinline__ int rx_training(RxState& st, uint64_t bits, int nv, int k0) {
+    if (st.phase == 1) return 0;
+    if (st.phase != 0) return -1;
     const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
     bits &= valid;
-    int start = 0;
-    if (st.phase == 0) {
-        // ref:386-390: window (b[k-3], b[k-2], b[k-1], b[k]) == (1,0,0,0)
-        const uint64_t h = st.hist;
-        const uint64_t b3 = (bits << 3) | (h & 7ull);
-        const uint64_t b2 = (bits << 2) | ((h >> 1) & 3ull);
-        const uint64_t b1 = (bits << 1) | ((h >> 2) & 1ull);
-        const uint64_t hit = b3 & ~b2 & ~b1 & ~bits & valid;
-        if (hit) {
-            const int j = __builtin_ctzll(hit);
-            st.term_sym = k0 + j + 1;
-            st.phase = 1;
-            start = j + 1;
-        } else {
-            st.hist = nv >= 3 ? (uint32_t)((bits >> (nv - 3)) & 7ull)
-                              : (uint32_t)(((h | (bits << 3)) >> nv) & 7ull);
-            return;
-        }
+    // window (b[k-3], b[k-2], b[k-1], b[k]) == (1,0,0,0)
+    const uint64_t h = st.hist;
+    const uint64_t b3 = (bits << 3) | (h & 7ull);
+    const uint64_t b2 = (bits << 2) | ((h >> 1) & 3ull);
+    const uint64_t b1 = (bits << 1) | ((h >> 2) & 1ull);
+    const uint64_t hit = b3 & ~b2 & ~b1 & ~bits & valid;
+    if (hit) {
+        const int j = __builtin_ctzll(hit);
+        st.term_sym = k0 + j + 1;
+        st.phase = 1;
+        return j + 1;
     }
-    if (st.phase != 1 || start >= nv) return;
-    // ref:372-378: take bits until the first symbol whose mean |x| < amp_end
+    st.hist = nv >= 3 ? (uint32_t)((bits >> (nv - 3)) & 7ull)
+                      : (uint32_t)(((h | (bits << 3)) >> nv) & 7ull);
+    return -1;
+}
+
+// Data part (ref:372-378) + Hamming decode + byte pack for the symbols [start, nv) of a pass.
+__device__ __forceinline__ void rx_data(RxState& st, uint64_t bits, uint64_t amp_ok, int start,
+                                        int nv, int lane, uint8_t* out_row, int out_stride) {
+    if (st.phase != 1 || start < 0 || start >= nv) return;
+    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    bits &= valid;
+    // take bits until the first symbol whose mean |x| < amp_end
     const uint64_t from = valid & ~((1ull << start) - 1ull);   // start < 64 here
     const uint64_t stop = from & ~amp_ok;
     int end = nv;
@@ -172,6 +178,13 @@ __device__ __forceinline__ void rx_consume(RxState& st, uint64_t bits, uint64_t 
     else rest = hi >> (used - 64);
     st.pend = (uint32_t)rest & ((1u << rem) - 1u);
     st.npend = rem;
+}
+
+// bits / amp_ok: bit j = decision of symbol k0+j (only j < nv meaningful).
+__device__ __forceinline__ void rx_consume(RxState& st, uint64_t bits, uint64_t amp_ok, int nv,
+                                           int k0, int lane, uint8_t* out_row, int out_stride) {
+    const int start = rx_training(st, bits, nv, k0);
+    rx_data(st, bits, amp_ok, start, nv, lane, out_row, out_stride);
 }
 
 // ------------------------------------------------------------------- phase A
@@ -446,7 +459,8 @@ namespace afsk {
 
 // FLAGS are diagnostic only (tools/kbench.hip); the product instantiates FLAGS = 0.
 constexpr int kFlagSkipSync = 1;    // force clock index 0, no phase A (results wrong unless ci == 0)
-constexpr int kFlagSkipValu = 2;    // phase B streams the ring but skips the per-sample VALU work
+constexpr int kFlagSkipValu = 2;
+constexpr int kFlagNoNt = 4;        // default cache policy instead of non-temporal (nt) ring DMA loads    // phase B streams the ring but skips the per-sample VALU work
 
 // FAST = use the stream-aligned single-pass path (afsk_demod_fast.h) for bit_frames 20/40/160;
 // every other valid bit_frames value takes the two-pass path below.

@@ -57,10 +57,10 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs = {
         {"v1 two-pass", launch_flags<0, false>, true},
-        {"v2 fast", launch_flags<0, true>, true},
-        {"v1 skip_sync", launch_flags<1, false>, true},
+        {"v2 fast (nt)", launch_flags<0, true>, true},
+        {"v2 fast default-policy", launch_flags<4, true>, true},
         {"v2 skip_sync", launch_flags<1, true>, true},
-        {"v1 skip_sync+valu", launch_flags<3, false>, false},
+        {"v2 skip_valu", launch_flags<2, true>, false},
         {"v2 skip_sync+valu", launch_flags<3, true>, false},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
