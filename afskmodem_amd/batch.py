@@ -110,11 +110,30 @@ class DemodResult:
         return self.cpu().payloads()
 
 
-def alloc_result(n_streams: int, out_stride: int, device) -> DemodResult:
+def flat_layout(n_streams: int, out_stride: int):
+    """Byte offsets of the six output arrays inside one flat allocation:
+    [bytes n*stride | nbytes | nbits | clock_idx | term_frame | status] (int32 parts 4-aligned)."""
+    nb = (n_streams * out_stride + 3) & ~3
+    offs = [0] + [nb + 4 * n_streams * k for k in range(5)]
+    return offs, nb + 20 * n_streams
+
+
+def views_of_flat(flat, n_streams: int, out_stride: int) -> "DemodResult":
     torch = _torch()
-    i32 = lambda: torch.empty(n_streams, dtype=torch.int32, device=device)  # noqa: E731
-    return DemodResult(torch.zeros((n_streams, out_stride), dtype=torch.uint8, device=device),
-                       i32(), i32(), i32(), i32(), i32())
+    offs, total = flat_layout(n_streams, out_stride)
+    assert flat.numel() == total and flat.dtype == torch.uint8
+    i32 = [flat[o: o + 4 * n_streams].view(torch.int32) for o in offs[1:]]
+    res = DemodResult(flat[: n_streams * out_stride].view(n_streams, out_stride), *i32)
+    res.flat = flat  # type: ignore[attr-defined]
+    return res
+
+
+def alloc_result(n_streams: int, out_stride: int, device) -> DemodResult:
+    """All six output arrays as views of ONE allocation (``res.flat``), so a multi-GPU gather
+    of a whole result is a single collective with no packing pass."""
+    torch = _torch()
+    _, total = flat_layout(n_streams, out_stride)
+    return views_of_flat(torch.zeros(total, dtype=torch.uint8, device=device), n_streams, out_stride)
 
 
 def uniform_layout(n_streams: int, stream_len: int, device):

@@ -35,12 +35,39 @@ def unpack_records(rec, stride: int):
                        meta[:, 4].contiguous())
 
 
+def gather_flat(res, n_total: int, group=None, out=None):
+    """Equal-shard fast path: ONE all_gather_into_tensor of ``res.flat`` (the single allocation
+    behind a DemodResult from ``batch.alloc_result``) and nothing else -- no packing kernels.
+    Returns a list of per-rank DemodResult views over the gathered buffer (rank r's streams are
+    ``shard_range(n_total, r, world)``).  ``out``: optional preallocated uint8 [world * flat]."""
+    import torch
+    import torch.distributed as dist
+    from .batch import views_of_flat
+    world = dist.get_world_size(group)
+    n_local, stride = int(res.bytes.shape[0]), int(res.bytes.shape[1])
+    assert n_total == n_local * world, "gather_flat needs equal shards"
+    flat = res.flat
+    if out is None:
+        out = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    return split_gathered(out, world, n_local, stride)
+
+
+def split_gathered(out, world: int, n_local: int, stride: int):
+    """Per-rank DemodResult views over a buffer filled by ``gather_flat`` (pure views; callers
+    in a hot loop create them once for a preallocated ``out`` and reuse them)."""
+    from .batch import views_of_flat
+    per = out.numel() // world
+    return [views_of_flat(out[r * per: (r + 1) * per], n_local, stride) for r in range(world)]
+
+
 def gather_results(res, n_total: int, group=None):
     """All-gather every rank's DemodResult into one covering all n_total streams.
 
     Every rank must hold the shard ``shard_range(n_total, rank, world)``.  Shards
     may differ by one stream, so rows are padded to the largest shard for the
-    single collective and trimmed afterwards.
+    single collective and trimmed afterwards.  (General form; ``gather_flat`` is the
+    zero-copy form for equal shards.)
     """
     import torch
     import torch.distributed as dist

@@ -51,6 +51,10 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=0)
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: all-gather the decoded records of G steps with one collective")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
     args = ap.parse_args()
 
     import torch
@@ -68,8 +72,10 @@ def main() -> None:
     _native.require_device()          # no GPU -> loud failure, never a CPU fallback
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_local, bauds, snr_db, desc = WORKLOADS[args.workload]
@@ -98,7 +104,16 @@ def main() -> None:
     torch.cuda.synchronize()
 
     stride = batch.out_stride_for(STREAM_LEN, int(bf_h.min()))
-    outs = [batch.alloc_result(n_local, stride, dev) for _ in range(2)]   # double buffer
+    # Output ring: 2 groups x G step slots, each slot one flat allocation (all six output arrays).
+    # For N > 1 the decoded records of every step are exchanged, G steps per collective
+    # ("fewer, larger collectives"): when a group of G steps has been launched, its G flat
+    # buffers -- contiguous in memory -- are all-gathered on a side stream while the other
+    # group is being filled.
+    G = max(1, args.gather_every)
+    _, flat_sz = batch.flat_layout(n_local, stride)
+    group_flat = [torch.zeros(G * flat_sz, dtype=torch.uint8, device=dev) for _ in range(2)]
+    outs = [[batch.views_of_flat(gf[k * flat_sz: (k + 1) * flat_sz], n_local, stride)
+             for k in range(G)] for gf in group_flat]
 
     lib = _native.lib()
     cur = torch.cuda.current_stream()
@@ -112,52 +127,67 @@ def main() -> None:
         if rc != 0:
             _native.check(rc)
 
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if use_dist else None
+    gath_bufs = ([torch.empty(world * G * flat_sz, dtype=torch.uint8, device=dev)
+                  for _ in range(2)] if use_dist else None)
     ready_ev = [torch.cuda.Event() for _ in range(2)]
     done_ev = [torch.cuda.Event() for _ in range(2)]
-    gathered = None
+    gathers = 0
+    last_slot = (0, 0)
+
+    def gather_group(grp: int) -> None:
+        nonlocal gathers
+        ready_ev[grp].record(cur)
+        comm.wait_event(ready_ev[grp])
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(gath_bufs[grp], group_flat[grp])
+            done_ev[grp].record(comm)
+        gathers += 1
 
     def step(i: int) -> None:
-        """Launch the demod of step i; for N > 1 all-gather its records on the comm stream so
-        that the gather of step i overlaps the kernel of step i+1 (double-buffered outputs)."""
-        nonlocal gathered
-        b = i & 1
-        o = outs[b]
-        if comm is not None and i >= 2:
-            cur.wait_event(done_ev[b])     # gather of step i-2 has finished reading buffer b
-        launch(o)
-        if comm is not None:
-            ready_ev[b].record(cur)
-            comm.wait_event(ready_ev[b])
-            with torch.cuda.stream(comm):
-                gathered = adist.gather_results(o, n_total)
-                done_ev[b].record(comm)
+        """Launch the demod of step i into slot (i % G) of group (i // G) % 2; after the last
+        slot of a group, gather the whole group on the comm stream (overlaps the next group)."""
+        nonlocal last_slot
+        grp, k = (i // G) & 1, i % G
+        if comm is not None and k == 0 and i >= 2 * G:
+            cur.wait_event(done_ev[grp])   # the gather that read this group 2G steps ago is done
+        launch(outs[grp][k])
+        last_slot = (grp, k)
+        if comm is not None and k == G - 1:
+            gather_group(grp)
+
+    def finish(n_steps: int) -> None:
+        """Gather a trailing partial group so that every step's records have been exchanged."""
+        if comm is not None and n_steps % G != 0:
+            gather_group(((n_steps - 1) // G) & 1)
 
     def fence() -> None:
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
+    finish(args.warmup)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(cur)
     for i in range(args.steps):
         step(i)
+    finish(args.steps)
     ev1.record(cur)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)   # avg launch duration incl. gaps
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- check + algorithmic bytes from the last step's outputs
-    res = outs[(args.steps - 1) & 1].cpu() if args.steps > 0 else outs[0].cpu()
+    res = outs[last_slot[0]][last_slot[1]].cpu()
     got_payloads = res.payloads()
     if snr_db is None:
         ok = sum(got_payloads[s] == payload_h[s, : plen_h[s]].tobytes() for s in range(n_local))
@@ -246,9 +276,16 @@ def main() -> None:
         out["match_rate"] = match / ns
         out["match_sample_streams"] = ns
 
+    if use_dist:
+        # the gathered copy of this rank's last step must equal its own outputs
+        grp, k = last_slot
+        mine = gath_bufs[grp][rank * G * flat_sz + k * flat_sz: rank * G * flat_sz + (k + 1) * flat_sz]
+        out["gather_check"] = bool(torch.equal(mine, group_flat[grp][k * flat_sz: (k + 1) * flat_sz]))
+        out["gathers_in_timed_region"] = (args.steps + G - 1) // G
+        out["config"]["gather_every_steps"] = G
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

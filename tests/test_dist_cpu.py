@@ -27,6 +27,32 @@ def _fake_result(begin, end, stride):
     return DemodResult(b.to(torch.uint8), idx % 35, idx * 14, idx % 4096, idx + 24160, idx % 3)
 
 
+def _flat_result(begin, end, stride):
+    """Same content as _fake_result but living in one flat allocation (batch.alloc_result layout)."""
+    from afskmodem_amd import batch
+    src = _fake_result(begin, end, stride)
+    res = batch.alloc_result(end - begin, stride, "cpu")
+    for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"):
+        getattr(res, f).copy_(getattr(src, f))
+    return res
+
+
+def _worker_flat(rank, world, port, n_total, stride, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = adist.shard_range(n_total, rank, world)
+    parts = adist.gather_flat(_flat_result(b, e, stride), n_total)
+    ok = len(parts) == world
+    for r, part in enumerate(parts):
+        rb, re_ = adist.shard_range(n_total, r, world)
+        want = _fake_result(rb, re_, stride)
+        ok = ok and all(torch.equal(getattr(part, f), getattr(want, f))
+                        for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"))
+    q.put((rank, ok, n_total))
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n_total, stride, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -60,12 +86,24 @@ def test_pack_unpack_roundtrip():
         assert torch.equal(getattr(back, f), getattr(r, f))
 
 
-@pytest.mark.parametrize("n_total", [64, 33])
-def test_gather_world2_gloo(n_total):
+def test_flat_layout_views():
+    from afskmodem_amd import batch
+    res = batch.alloc_result(7, 12, "cpu")
+    offs, total = batch.flat_layout(7, 12)
+    assert res.flat.numel() == total == 84 + 5 * 28
+    res.nbits.fill_(3)
+    res.bytes.fill_(9)
+    assert int(res.flat[offs[2]: offs[2] + 4].view(torch.int32)[0]) == 3
+    assert res.flat[:84].eq(9).all() and res.status.eq(0).all()
+
+
+@pytest.mark.parametrize("n_total,worker", [(64, "pad"), (33, "pad"), (64, "flat")])
+def test_gather_world2_gloo(n_total, worker):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, 40, q)) for r in range(2)]
+    target = _worker if worker == "pad" else _worker_flat
+    procs = [ctx.Process(target=target, args=(r, 2, port, n_total, 40, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
