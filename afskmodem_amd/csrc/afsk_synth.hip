@@ -28,58 +28,96 @@ __device__ __forceinline__ uint32_t hamming_encode_bit(uint32_t nib, int pos) {
     }
 }
 
-__device__ __forceinline__ int16_t tone_sample(bool mark, int ph, int q, int h) {
-    const bool hi = mark ? (((ph / q) & 1) == 0) : (ph < h);   // ref:68-85
-    return hi ? (int16_t)32767 : (int16_t)-32768;
-}
+// Symbol layout of the ideal frame list (ref:452-469), in symbols of bf frames:
+//   [0, 2*ts)            training cycles: mark, space, mark, space ...        ref:457-458
+//   [2*ts, 2*ts + 4)     terminator: mark, space, space, space               ref:460-462
+//   [2*ts + 4, n_sym)    one symbol per Hamming-coded payload bit            ref:463-467
+// followed by 4800 zero frames (ref:468) and zero padding.
+struct SymbolMap {
+    uint32_t n_train_sym, n_sym;
+    const uint8_t* payload;
 
-__device__ __forceinline__ int16_t frame_value(int64_t f, int bf, int64_t n_train,
-                                               int64_t n_total_tones, const uint8_t* payload) {
-    // f indexes the ideal frame list of ref:452-469 (before the wav quirk)
-    const int q = bf >> 2, h = bf >> 1;
-    if (f < n_train) {                       // ref:457-458 training cycles: mark, space
-        const int ph = (int)(f % (2 * bf));
-        return ph < bf ? tone_sample(true, ph, q, h) : tone_sample(false, ph - bf, q, h);
+    // true = mark tone, false = space tone, for symbol index S < n_sym
+    __device__ __forceinline__ bool is_mark(uint32_t S, uint32_t byte_lo, uint32_t byte_hi,
+                                            uint32_t first_byte) const {
+        if (S < n_train_sym) return (S & 1u) == 0;
+        const uint32_t t = S - n_train_sym;
+        if (t < 4) return t == 0;
+        const uint32_t b = t - 4;                  // coded bit index
+        const uint32_t cw = b / 7u;                // nibble index
+        const uint32_t pos = b - cw * 7u;
+        const uint32_t byte = ((cw >> 1) == first_byte) ? byte_lo : byte_hi;
+        const uint32_t nib = (cw & 1u) ? (byte & 15u) : (byte >> 4);   // ref:446-450 MSB first
+        return hamming_encode_bit(nib, (int)pos) != 0;
     }
-    if (f >= n_total_tones) return 0;        // ref:468 tail silence (and zero padding)
-    const int64_t g = f - n_train;
-    const int64_t sym = g / bf;
-    const int ph = (int)(g - sym * bf);
-    if (sym < 4) return tone_sample(sym == 0, ph, q, h);   // ref:460-462 terminator
-    const int64_t b = sym - 4;               // coded bit index, ref:463-467
-    const int64_t cw = b / 7;
-    const int pos = (int)(b - cw * 7);
-    const uint8_t byte = payload[cw >> 1];
-    const uint32_t nib = (cw & 1) ? (byte & 15u) : (byte >> 4);   // ref:446-450 MSB first
-    return tone_sample(hamming_encode_bit(nib, pos) != 0, ph, q, h);
-}
+};
 
+// One thread = 8 consecutive output samples = one 16-byte store.  All positions fit in
+// 32 bits (stream_len < 2^30).  One integer division locates the first frame's symbol; the
+// thread touches at most 3 symbols (bf >= 4), whose tone kinds are resolved up front.
 __global__ __launch_bounds__(256) void modulate_kernel(ModulateArgs a) {
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
-    const int32_t len = a.stream_len[s];
-    const int64_t p0 = ((int64_t)chunk * blockDim.x + threadIdx.x) * 8;
+    const uint32_t len = (uint32_t)a.stream_len[s];
+    const uint32_t p0 = ((uint32_t)chunk * blockDim.x + threadIdx.x) * 8u;
     if (p0 >= len) return;
-    const int bf = a.bit_frames[s];
-    const int64_t n_train = (int64_t)a.ts_cycles[s] * 2 * bf;
-    const int64_t n_tones = n_train + (int64_t)(4 + 14 * (int64_t)a.payload_len[s]) * bf;
-    const int64_t n_frames = n_tones + 4800;
+    const uint32_t bf = (uint32_t)a.bit_frames[s];
+    const uint32_t plen = (uint32_t)a.payload_len[s];
+    SymbolMap m;
+    m.n_train_sym = 2u * (uint32_t)a.ts_cycles[s];
+    m.n_sym = m.n_train_sym + 4u + 14u * plen;
+    m.payload = a.payload + (int64_t)s * a.payload_stride;
+    const uint64_t n_tones64 = (uint64_t)m.n_sym * bf;
+    const uint64_t n_frames64 = n_tones64 + 4800u;
     // wav quirk ref:239-244: out[2i] = out[2i+1] = frames[2i] for 2i < n_frames - 1
-    const int64_t n_out = a.wav_quirk ? (n_frames & ~1ll) : n_frames;
-    const uint8_t* payload = a.payload + (int64_t)s * a.payload_stride;
+    const uint64_t n_out64 = a.wav_quirk ? (n_frames64 & ~1ull) : n_frames64;
+    const uint32_t n_tones = n_tones64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_tones64;
+    const uint32_t n_out = n_out64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_out64;
     int16_t* dst = a.samples + a.stream_offset[s] + p0;
+
+    const uint32_t S0 = p0 / bf;
+    uint32_t ph = p0 - S0 * bf;
+    // payload bytes the (at most three) symbols S0..S0+2 can need
+    uint32_t first_byte = 0, byte_lo = 0, byte_hi = 0;
+    if (S0 + 2 >= m.n_train_sym + 4u && plen > 0) {
+        const uint32_t b0 = S0 > m.n_train_sym + 4u ? S0 - (m.n_train_sym + 4u) : 0u;
+        first_byte = (b0 / 7u) >> 1;
+        if (first_byte < plen) byte_lo = m.payload[first_byte];
+        if (first_byte + 1 < plen) byte_hi = m.payload[first_byte + 1];
+    }
+    bool kind[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        kind[k] = (S0 + k < m.n_sym) ? m.is_mark(S0 + k, byte_lo, byte_hi, first_byte) : false;
+
+    const uint32_t step = a.wav_quirk ? 2u : 1u;
     pack8 v;
+    uint32_t wraps = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int64_t p = p0 + j;
-        int16_t val = 0;
-        if (p < n_out) val = frame_value(a.wav_quirk ? (p & ~1ll) : p, bf, n_train, n_tones, payload);
-        v.v[j] = val;
+        const uint32_t p = p0 + j;
+        const bool fresh = a.wav_quirk ? ((j & 1) == 0) : true;   // odd outputs repeat the even frame
+        if (fresh) {
+            int16_t val = 0;
+            if (p < n_tones && p < n_out) {
+                const bool mark = wraps == 0 ? kind[0] : (wraps == 1 ? kind[1] : kind[2]);
+                const uint32_t ph4 = 4u * ph;
+                const bool hi_mark = (ph4 < bf) || (ph4 >= 2u * bf && ph4 < 3u * bf);   // ref:80-85
+                const bool hi_space = 2u * ph < bf;                                      // ref:68-77
+                val = (mark ? hi_mark : hi_space) ? (int16_t)32767 : (int16_t)-32768;
+            }
+            v.v[j] = val;
+            ph += step;
+            if (ph >= bf) { ph -= bf; wraps++; }
+            if (ph >= bf) { ph -= bf; wraps++; }   // step 2 with bf == ... keeps ph < bf (bf >= 4)
+        } else {
+            v.v[j] = (p < n_out) ? v.v[j - 1] : (int16_t)0;
+        }
     }
-    if (p0 + 8 <= len) {
+    if (p0 + 8u <= len) {
         *reinterpret_cast<pack8*>(dst) = v;
     } else {
-        for (int j = 0; j < 8 && p0 + j < len; j++) dst[j] = v.v[j];
+        for (uint32_t j = 0; j < 8u && p0 + j < len; j++) dst[j] = v.v[j];
     }
 }
 

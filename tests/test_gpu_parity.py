@@ -163,6 +163,13 @@ def test_modulator_and_noise_match_oracle(torch_cuda):
     want2 = O.modulate_batch(b2["payload"], b2["plen"], b2["h_bf"], b2["ts"], b2["h_off"],
                              b2["h_ln"], 6 * b2["total"], False)
     assert np.array_equal(b2["samples"].cpu().numpy(), want2)
+    # every other valid baud, short training, ragged totals (truncation inside tones / tail)
+    for total, tt in ((48000, 0.5), (9001, 0.1), (2500, 0.02)):
+        b4 = synth_batch(torch, 24, (100, 600, 4000, 6000, 480, 2000, 1500, 12000), seed=15,
+                         total=total, training_time=tt, payload_len=3)
+        want4 = O.modulate_batch(b4["payload"], b4["plen"], b4["h_bf"], b4["ts"], b4["h_off"],
+                                 b4["h_ln"], 24 * total, True)
+        assert np.array_equal(b4["samples"].cpu().numpy(), want4), (total, tt)
     # noise generator: identical integers on CPU and GPU
     snr = [30, 10, 5, 0]
     b3 = synth_batch(torch, 4, (1200,), seed=13, snr_db=snr)

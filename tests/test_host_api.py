@@ -187,3 +187,23 @@ def test_product_package_never_imports_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
                 assert "libafsk_oracle" not in text and "afsk_oracle.h" not in text, fn
+
+
+def test_device_api_needs_a_gpu_and_checks_types():
+    """batch.demod_batch never degrades to a host path: no GPU -> AfskNativeError."""
+    import torch
+    x = torch.zeros(48000, dtype=torch.int16)
+    off = torch.zeros(1, dtype=torch.int64)
+    ln = torch.full((1,), 48000, dtype=torch.int32)
+    if _native.device_count() == 0:
+        with pytest.raises(_native.AfskNativeError):
+            batch.demod_batch(x, off, ln, 40, out_stride=64)
+    else:
+        with pytest.raises(TypeError):
+            batch.demod_batch(x, off, ln, 40, out_stride=64)   # CPU tensor rejected
+
+
+def test_out_stride_never_truncates():
+    for L, bf in ((48000, 20), (48000, 40), (48000, 160), (4096, 4), (10 ** 6, 8)):
+        assert batch.out_stride_for(L, bf) >= L // (14 * bf) + 1
+        assert batch.out_stride_for(L, bf) % 4 == 0

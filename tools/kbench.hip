@@ -49,6 +49,14 @@ int main(int argc, char** argv) {
     afsk::ModulateArgs m{d_payload, plen_v, d_pl, d_bf, d_ts, d_off, d_len, n, 1, d_x, 0};
     CK(afsk::launch_modulate(m, L, 0));
     CK(hipDeviceSynchronize());
+    {   // modulator timing (write-bound, 2 B per sample)
+        hipEvent_t m0, m1; CK(hipEventCreate(&m0)); CK(hipEventCreate(&m1));
+        CK(hipEventRecord(m0, 0));
+        for (int k = 0; k < 5; k++) CK(afsk::launch_modulate(m, L, 0));
+        CK(hipEventRecord(m1, 0)); CK(hipEventSynchronize(m1));
+        float ms; CK(hipEventElapsedTime(&ms, m0, m1));
+        printf("modulate_kernel: %.1f us per launch, %.2f TB/s written\n", ms / 5 * 1e3, 2.0 * n * L / (ms / 5 * 1e-3) / 1e12);
+    }
 
     const int stride = 72;
     uint8_t* d_ob; int32_t* d_i32;
