@@ -200,6 +200,69 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
     return out
 
 
+@dataclass
+class GateResult:
+    """Device-resident outputs of ``gate_batch`` (torch tensors)."""
+    n_bursts: "object"       # int32 [n]
+    burst_start: "object"    # int32 [n, max_bursts], samples from the stream start
+    burst_len: "object"      # int32 [n, max_bursts], multiples of 2048
+    open_end: "object"       # int32 [n]
+    block_amp: "object"      # int32 [n, max_blocks]: int(sum|x| / 2048) per 2048-frame block
+
+    def burst_streams(self, stream_offset):
+        """Flatten the bursts into (owner_stream int64 [m], offset int64 [m], length int32 [m])
+        device tensors ready for ``demod_batch`` (capture order, then burst order)."""
+        torch = _torch()
+        nb = self.burst_start.shape[1]
+        mask = torch.arange(nb, device=self.n_bursts.device)[None, :] < self.n_bursts[:, None]
+        owner, k = torch.nonzero(mask, as_tuple=True)
+        off = stream_offset[owner] + self.burst_start[owner, k].to(torch.int64)
+        return owner, off.contiguous(), self.burst_len[owner, k].contiguous()
+
+
+def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
+               amp_start_threshold: int = 18000, amp_end_threshold: int = 14000,
+               max_bursts: int = 16, stream=None) -> GateResult:
+    """Replay ``Receiver.__listen`` (ref:299-319) over n captures resident in HBM: 2048-frame
+    block amplitudes, start above ``amp_start_threshold``, stop at the first block below
+    ``amp_end_threshold``; repeated receive() calls until each capture is exhausted."""
+    torch = _torch()
+    _native.require_device()
+    if not (isinstance(samples, torch.Tensor) and samples.is_cuda and samples.dtype == torch.int16
+            and samples.is_contiguous()):
+        raise TypeError("samples must be a contiguous int16 CUDA tensor")
+    if stream_offset.dtype != torch.int64 or stream_len.dtype != torch.int32:
+        raise TypeError("stream_offset must be int64 and stream_len int32")
+    n = int(stream_offset.numel())
+    dev = samples.device
+    max_blocks = int(max_stream_len) // 2048
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)  # noqa: E731
+    res = GateResult(i32(n), i32(n, max(max_bursts, 1)), i32(n, max(max_bursts, 1)), i32(n),
+                     i32(n, max(max_blocks, 1)))
+    _native.check(_native.lib().afsk_gate_batch(
+        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
+        int(amp_start_threshold), int(amp_end_threshold), n, int(max_bursts),
+        res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
+        res.burst_len.data_ptr(), res.open_end.data_ptr(), _stream_ptr(stream)))
+    return res
+
+
+def upload_streams(arrays, device="cuda:0"):
+    """Host int16 arrays (ragged) -> (samples, stream_offset, stream_len, max_len) on the device,
+    stream-major and back to back (the layout every kernel expects)."""
+    torch = _torch()
+    lens = np.array([len(a) for a in arrays], dtype=np.int32)
+    offs = np.zeros(len(arrays), dtype=np.int64)
+    if len(arrays) > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    flat = (np.concatenate([np.ascontiguousarray(a, dtype=np.int16) for a in arrays])
+            if len(arrays) else np.zeros(0, np.int16))
+    if flat.size == 0:
+        flat = np.zeros(1, np.int16)
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return t(flat), t(offs), t(lens), int(lens.max()) if len(arrays) else 0
+
+
 def modulate_batch(payload, payload_len, bit_frames, ts_cycles, stream_offset, stream_len,
                    max_stream_len: int, samples, wav_quirk: bool = True, stream=None) -> None:
     """On-device Transmitter.__getFrames + .wav quirk (ref:452-469, 239-244) into ``samples``.

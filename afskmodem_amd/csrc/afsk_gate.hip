@@ -1,0 +1,89 @@
+// afsk_gate.hip -- batched replay of Receiver.__listen (reference afskmodem.py:299-319): the
+// 2048-frame block amplitude gate that cuts bursts out of a continuous capture before they are
+// demodulated.  Two kernels:
+//
+//   block_amp_kernel  one wavefront per 2048-sample block: four coalesced 16-byte loads per
+//                     lane, v_sad_u16 accumulation of |x| (ref:94-98), DPP wave reduction,
+//                     amp = sum >> 11 (= int(sum / 2048)).  HBM-bound, 2 B per sample.
+//   gate_scan_kernel  one thread per capture walks its block amplitudes through the
+//                     listen state machine: discard one block (ref:303), wait for
+//                     amp > amp_start (ref:306), record through the first amp < amp_end
+//                     (ref:316), repeat for the next receive() call.
+#include "afsk_kernels.h"
+
+namespace afsk {
+
+constexpr int kListenBlock = 2048;   // ref:189, 209, 310
+
+struct __attribute__((packed, aligned(2))) vec16 { uint32_t v[4]; };
+
+__global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave = block slot
+    const int s = (int)(w / a.max_blocks);
+    if (s >= a.n_streams) return;
+    const int b = (int)(w - (int64_t)s * a.max_blocks);
+    const int32_t nb = a.stream_len[s] / kListenBlock;
+    if (b >= nb) return;
+    const int16_t* src = a.samples + a.stream_offset[s] + (int64_t)b * kListenBlock;
+    uint32_t acc = 0;
+    vec16 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const vec16*>(src + 512 * j + 8 * lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            acc = __builtin_amdgcn_sad_u16(v[j].v[k] ^ 0x80008000u, 0x80008000u, acc);   // sum |x|
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
+    if (lane == 0) a.block_amp[(int64_t)s * a.max_blocks + b] = (int32_t)(acc >> 11);    // int(sum/2048)
+}
+
+__global__ __launch_bounds__(256) void gate_scan_kernel(GateArgs a) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_streams) return;
+    const int32_t nb = a.stream_len[s] / kListenBlock;
+    const int32_t* amp = a.block_amp + (int64_t)s * a.max_blocks;
+    int32_t* bs = a.out_burst_start + (int64_t)s * a.max_bursts;
+    int32_t* bl = a.out_burst_len + (int64_t)s * a.max_bursts;
+    int n = 0, open_end = 0;
+    int mode = 0;                 // 0 = discard next block, 1 = wait for start, 2 = recording
+    int start = 0;
+    for (int b = 0; b < nb && n < a.max_bursts; b++) {
+        if (mode == 0) { mode = 1; continue; }                       // ref:303
+        const int32_t v = amp[b];
+        if (mode == 1) {
+            if (v > a.amp_start) { start = b; mode = 2; }            // ref:306-309
+        } else if (v < a.amp_end) {                                  // ref:316-318 (block included)
+            bs[n] = start * kListenBlock;
+            bl[n] = (b - start + 1) * kListenBlock;
+            n++;
+            mode = 0;
+        }
+    }
+    if (mode == 2 && n < a.max_bursts) {     // capture ended while recording: open-ended burst
+        bs[n] = start * kListenBlock;
+        bl[n] = (nb - start) * kListenBlock;
+        n++;
+        open_end = 1;
+    }
+    a.out_n_bursts[s] = n;
+    a.out_open_end[s] = open_end;
+}
+
+hipError_t launch_gate(const GateArgs& a, hipStream_t stream) {
+    if (a.n_streams <= 0) return hipSuccess;
+    if (a.max_blocks > 0) {
+        const int64_t waves = (int64_t)a.n_streams * a.max_blocks;
+        const int64_t blocks = (waves + 3) / 4;
+        if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(block_amp_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(gate_scan_kernel, dim3((a.n_streams + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace afsk

@@ -46,6 +46,23 @@ struct NoiseArgs {
     int32_t chunks;
 };
 
+struct GateArgs {
+    const int16_t* samples;
+    const int64_t* stream_offset;
+    const int32_t* stream_len;
+    int32_t amp_start;
+    int32_t amp_end;
+    int32_t n_streams;
+    int32_t max_blocks;     // workspace row length = max_stream_len / 2048
+    int32_t max_bursts;
+    int32_t* block_amp;     // [n_streams, max_blocks]
+    int32_t* out_n_bursts;
+    int32_t* out_burst_start;
+    int32_t* out_burst_len;
+    int32_t* out_open_end;
+};
+
+hipError_t launch_gate(const GateArgs& a, hipStream_t stream);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);
 hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream);

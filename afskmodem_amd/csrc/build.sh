@@ -4,5 +4,5 @@ set -euo pipefail
 cd "$(dirname "$0")"
 ARCH=${AFSK_ARCH:-gfx950}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
-hipcc ${FLAGS} -shared -o libafsk_amd.so afsk_capi.hip afsk_demod.hip afsk_synth.hip "$@"
+hipcc ${FLAGS} -shared -o libafsk_amd.so afsk_capi.hip afsk_demod.hip afsk_synth.hip afsk_gate.hip "$@"
 echo "built $(pwd)/libafsk_amd.so"

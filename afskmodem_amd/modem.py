@@ -391,6 +391,32 @@ class Receiver:
     def load_batch(self, filenames, string: bool = False):
         return self.decode_batch([SoundInput.loadArrayFromFile(f) for f in filenames], string)
 
+    def decode_captures(self, captures, max_bursts: int = 16, string: bool = False):
+        """What repeated ``receive()`` calls would return if each capture (a long int16
+        recording) were played into the audio input: the live gate of ``__listen``
+        (ref:299-319, thresholds of this Receiver) cuts the bursts, then every burst is
+        demodulated -- both on the GPU.  Returns one list of payloads per capture."""
+        import torch
+        from . import batch
+        arrays = [np.ascontiguousarray(c, dtype=np.int16) for c in captures]
+        if not arrays:
+            return []
+        samples, off, ln, max_len = batch.upload_streams(arrays)
+        gate = batch.gate_batch(samples, off, ln, max_len, self.__amp_start_threshold,
+                                self.__amp_end_threshold, max_bursts)
+        owner, b_off, b_len = gate.burst_streams(off)
+        out: list[list] = [[] for _ in arrays]
+        if owner.numel() == 0:
+            return out
+        self.check_decodable(int(b_len.max()))
+        stride = batch.out_stride_for(int(b_len.max()), self.__bit_frames)
+        res = batch.demod_batch(samples, b_off, b_len, self.__bit_frames, self.__amp_end_threshold,
+                                out_stride=stride)
+        torch.cuda.synchronize()
+        for o, data in zip(owner.cpu().tolist(), res.payloads()):
+            out[o].append(data.decode("utf-8") if (string and data != b"") else data)
+        return out
+
 
 # --------------------------------------------------------------- Transmitter
 

@@ -116,6 +116,31 @@ int afsk_modulate_batch(const uint8_t *payload, int32_t payload_stride,
                         int32_t wav_quirk, int16_t *samples, void *hip_stream);
 
 /*
+ * Batched replay of Receiver.__listen (:299-319) over finite captures: the live-input gate
+ * that decides which 2048-frame blocks (:189, :209) of a continuous recording are handed to
+ * __decodeBits.  Per capture, repeated receive() calls are emulated: each call discards one
+ * block (:303), waits for a block with getAmplitude > amp_start_threshold (:306) and records
+ * blocks up to and including the first one with getAmplitude < amp_end_threshold (:316).
+ * Only whole blocks of the capture are considered (no timeout: the call scans to the end).
+ *
+ *  max_stream_len   host-side upper bound of stream_len[]; max_blocks = max_stream_len / 2048
+ *  block_amp        workspace AND output, int32 [n, max_blocks]: int(sum|x| / 2048) per block
+ *  out_n_bursts     [n] bursts found (<= max_bursts)
+ *  out_burst_start  [n, max_bursts] first sample of burst k, relative to the stream start
+ *  out_burst_len    [n, max_bursts] samples in burst k (a multiple of 2048)
+ *  out_open_end     [n] 1 when the last burst reached the end of the capture without a quiet
+ *                   block (a live receiver would still be recording)
+ * The bursts are demodulated by passing stream_offset[s] + out_burst_start[s,k] and
+ * out_burst_len[s,k] to afsk_demod_batch.
+ */
+int afsk_gate_batch(const int16_t *samples, const int64_t *stream_offset,
+                    const int32_t *stream_len, int32_t max_stream_len,
+                    int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
+                    int32_t max_bursts, int32_t *block_amp, int32_t *out_n_bursts,
+                    int32_t *out_burst_start, int32_t *out_burst_len, int32_t *out_open_end,
+                    void *hip_stream);
+
+/*
  * Deterministic additive noise (build-owned test/benchmark input generator, no
  * reference counterpart): per sample an Irwin-Hall sum of 16 uniform u16 drawn
  * from a counter hash of (seed, stream_idx_base + s, sample index), centred,

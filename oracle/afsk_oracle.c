@@ -320,6 +320,39 @@ int64_t afsk_o_wav_convert(const int16_t *in, int64_t n, int16_t *out) {
     return o;
 }
 
+/* ------------------------------------------------------------- live gate replay */
+
+#define LISTEN_BLOCK 2048  /* ref:189, 209, 310 */
+
+int32_t afsk_o_gate_stream(const int16_t *frames, int64_t len, int32_t amp_start_threshold,
+                           int32_t amp_end_threshold, int32_t max_bursts, int32_t *burst_start,
+                           int32_t *burst_len, int32_t *open_end) {
+    const int64_t nb = len / LISTEN_BLOCK;
+    int64_t b = 0;
+    int32_t n = 0;
+    *open_end = 0;
+    while (n < max_bursts) {
+        b += 1;                                                     /* ref:303 discard */
+        while (b < nb &&
+               !(afsk_o_get_amplitude(frames + b * LISTEN_BLOCK, LISTEN_BLOCK) > amp_start_threshold))
+            b++;                                                    /* ref:304-310 */
+        if (b >= nb) break;
+        const int64_t start = b;                                    /* ref:307-309 */
+        b++;
+        int quiet = 0;
+        while (b < nb) {                                            /* ref:313-318 */
+            quiet = afsk_o_get_amplitude(frames + b * LISTEN_BLOCK, LISTEN_BLOCK) < amp_end_threshold;
+            b++;
+            if (quiet) break;
+        }
+        burst_start[n] = (int32_t)(start * LISTEN_BLOCK);
+        burst_len[n] = (int32_t)((b - start) * LISTEN_BLOCK);
+        n++;
+        if (!quiet) { *open_end = 1; break; }
+    }
+    return n;
+}
+
 /* ------------------------------------------------------- deterministic noise */
 
 static inline uint32_t hash32(uint32_t x) {

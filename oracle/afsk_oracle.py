@@ -71,6 +71,9 @@ def lib() -> C.CDLL:
         L.afsk_o_wav_convert.restype = C.c_int64
         L.afsk_o_add_noise.argtypes = [i16p, C.c_int64, C.c_uint32, C.c_uint32, C.c_int32]
         L.afsk_o_add_noise.restype = None
+        L.afsk_o_gate_stream.argtypes = [i16p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, i32p, i32p,
+                                         i32p]
+        L.afsk_o_gate_stream.restype = C.c_int32
         L.afsk_o_demod_batch.argtypes = [i16p, i64p, i32p, i32p, C.c_int32, C.c_int32, u8p,
                                          C.c_int32, i32p, i32p, i32p, i32p, i32p, C.c_int32]
         L.afsk_o_modulate_batch.argtypes = [u8p, C.c_int32, i32p, i32p, i32p, i64p, i32p,
@@ -259,6 +262,19 @@ def modulate_batch(payload: np.ndarray, payload_len, bit_frames, ts_cycles, stre
                                        _p(ln, C.c_int32), n, 1 if wav_quirk else 0,
                                        _p(out, C.c_int16)))
     return out
+
+
+def gate_stream(frames, amp_start_threshold: int = 18000, amp_end_threshold: int = 14000,
+                max_bursts: int = 16):
+    """Receiver.__listen (ref:299-319) replayed over a capture -> ([(start, length)...], open_end)."""
+    f = _i16(frames)
+    st = np.zeros(max_bursts, np.int32)
+    ln = np.zeros(max_bursts, np.int32)
+    oe = C.c_int32(0)
+    n = lib().afsk_o_gate_stream(_p(f, C.c_int16), f.size, int(amp_start_threshold),
+                                 int(amp_end_threshold), int(max_bursts), _p(st, C.c_int32),
+                                 _p(ln, C.c_int32), C.byref(oe))
+    return [(int(st[i]), int(ln[i])) for i in range(n)], int(oe.value)
 
 
 def load_frames(frames, baud: int = 1200, amp_end_threshold: int = 14000) -> bytes:

@@ -39,10 +39,20 @@ def import_reference():
     stub.paInt16 = 8
 
     class _Stream:
+        # capture replayed to Receiver.__listen: FEED["data"] (int16 bytes) then silence forever
+        FEED = {"data": b"", "served": 0}
+
         def start_stream(self): pass
         def stop_stream(self): pass
         def close(self): pass
-        def read(self, n): return b"\x00\x00" * n
+
+        def read(self, n):
+            f = _Stream.FEED
+            lo = f["served"] * 2
+            chunk = f["data"][lo: lo + 2 * n]
+            f["served"] += n
+            return chunk + b"\x00" * (2 * n - len(chunk))
+
         def write(self, *a, **k): pass
 
     class _PA:
@@ -296,6 +306,66 @@ def main():
                  gen={"kind": "wav", "payload_hex": data.hex(), "baud": baud,
                       "training_time": 0.5, "total": None})
     G["decode_cases"] = cases
+
+    # ---- 5b. live gate (Receiver.__listen ref:299-319) replayed over finite captures
+    rng2 = np.random.default_rng(99)
+    stream_cls = sys.modules["pyaudio"].Stream
+    from tests.golden_inputs import build_capture
+
+    pa, pb_, pc = (rng2.integers(0, 256, k, dtype=np.uint8).tobytes().hex() for k in (5, 9, 3))
+    NF = 1200000   # noise scale_q24: mean |x| of a few thousand (below both squelch thresholds)
+    recipes = {
+        "two_bursts_silence": [["zeros", 5000], ["burst", pa, 1200, 0.1, None], ["zeros", 9000],
+                               ["burst", pb_, 1200, 0.1, None], ["zeros", 3000]],
+        "three_bursts_noise_floor": [["noise", 7000, 1, NF], ["burst", pa, 1200, 0.1, None],
+                                     ["noise", 6500, 2, NF], ["burst", pb_, 1200, 0.1, None],
+                                     ["noise", 2100, 3, NF], ["burst", pc, 1200, 0.1, None],
+                                     ["noise", 8000, 4, NF]],
+        "burst_at_zero": [["burst", pa, 1200, 0.1, None], ["zeros", 6000], ["burst", pc, 1200, 0.1, None],
+                          ["zeros", 5000]],
+        "no_burst": [["noise", 30000, 5, NF]],
+        "between_thresholds": [["zeros", 4096], ["square", 8192, 16000], ["burst", pb_, 1200, 0.1, None],
+                               ["square", 6000, 16000], ["zeros", 6000]],
+        "open_end": [["zeros", 3000], ["burst", pa, 1200, 0.1, 9000]],
+        "short_gap_merge": [["zeros", 2500], ["burst", pa, 1200, 0.1, 7760], ["zeros", 900],
+                            ["burst", pb_, 1200, 0.1, None], ["zeros", 7000]],
+        "partial_last_block": [["zeros", 2048], ["burst", pc, 1200, 0.1, None], ["zeros", 2048 + 777]],
+    }
+    captures = {k: build_capture(v) for k, v in recipes.items()}
+    listen_cases = []
+    for name, cap in captures.items():
+        cap = np.ascontiguousarray(cap, dtype=np.int16)
+        nb = len(cap) // 2048
+        for (a_start, a_end) in ((18000, 14000), (9000, 2500)):
+            stream_cls.FEED["data"] = cap.astype("<i2").tobytes()
+            stream_cls.FEED["served"] = 0
+            r = ref.Receiver(1200, a_start, a_end)
+            bursts = []
+            open_end = 0
+            for _ in range(16):
+                served_blocks = stream_cls.FEED["served"] // 2048
+                if served_blocks >= nb:
+                    break
+                rec = r._Receiver__listen((nb - served_blocks + 4) * 2048)
+                if rec == []:
+                    break
+                end_block = stream_cls.FEED["served"] // 2048        # blocks consumed so far
+                start_block = end_block - len(rec) // 2048
+                length = len(rec)
+                if end_block > nb:                                   # ran into the virtual silence
+                    length = (nb - start_block) * 2048
+                    open_end = 1
+                bits = r._Receiver__decodeBits(rec)
+                data = b"" if bits == "" else r._Receiver__bitsToBytes(ref.ECC.decode(bits))
+                bursts.append({"start": start_block * 2048, "len": length, "ref_len": len(rec),
+                               "bytes_hex": data.hex()})
+                if open_end:
+                    break
+            listen_cases.append({"name": name, "amp_start": a_start, "amp_end": a_end,
+                                 "n_samples": len(cap), "capture_sha256": sha(cap),
+                                 "recipe": recipes[name],
+                                 "bursts": bursts, "open_end": open_end})
+    G["listen_cases"] = listen_cases
 
     # ---- 6. README assertion (README.md:47-66)
     fn = os.path.join(tmpdir, "afsk.wav")

@@ -47,3 +47,25 @@ def build_input(case: dict) -> np.ndarray:
     assert len(x) == case["n_samples"], (case["tag"], len(x), case["n_samples"])
     assert sha_i16(x) == case["input_sha256"], case["tag"]
     return x
+
+
+def build_capture(recipe) -> np.ndarray:
+    """A long capture from a list of segments (used by the live-gate cases):
+    ["zeros", n] | ["noise", n, seed, scale_q24] (oracle integer noise on silence) |
+    ["burst", payload_hex, baud, training_time, keep] (wav samples, first `keep` if not None) |
+    ["square", n, amplitude] (+a, -a, +a, ...)."""
+    parts = []
+    for seg in recipe:
+        kind = seg[0]
+        if kind == "zeros":
+            parts.append(np.zeros(seg[1], np.int16))
+        elif kind == "noise":
+            parts.append(O.add_noise(np.zeros(seg[1], np.int16), seg[2], 0, seg[3]))
+        elif kind == "burst":
+            w = _wav(seg[1], seg[2], seg[3])
+            parts.append(w if seg[4] is None else w[: seg[4]])
+        elif kind == "square":
+            parts.append(np.tile(np.array([seg[2], -seg[2]], np.int16), seg[1] // 2))
+        else:
+            raise ValueError(kind)
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.int16)

@@ -312,3 +312,47 @@ def test_full_size_config2_roundtrip(torch_cuda):
     sub = batch.HostDemodResult(got.bytes[sel], got.nbytes[sel], got.nbits[sel],
                                 got.clock_idx[sel], got.term_frame[sel], got.status[sel])
     assert_same(sub, want, "config2 sample")
+
+
+def test_listen_gate_vs_reference_and_oracle(golden, torch_cuda):
+    """Row f2: the block-amplitude gate on the GPU against the reference-recorded burst boundaries
+    (golden) and the oracle, then gate -> demod end to end through Receiver.decode_captures."""
+    from tests.golden_inputs import build_capture
+    torch = torch_cuda
+    for a_start, a_end in ((18000, 14000), (9000, 2500)):
+        cases = [c for c in golden["listen_cases"] if c["amp_start"] == a_start]
+        caps = [build_capture(c["recipe"]) for c in cases]
+        samples, off, ln, max_len = batch.upload_streams(caps)
+        g = batch.gate_batch(samples, off, ln, max_len, a_start, a_end, 16)
+        torch.cuda.synchronize()
+        nb, bs, bl, oe, amp = (t.cpu().numpy() for t in (g.n_bursts, g.burst_start, g.burst_len,
+                                                          g.open_end, g.block_amp))
+        for i, c in enumerate(cases):
+            want = [(b["start"], b["len"]) for b in c["bursts"]]
+            got = [(int(bs[i, k]), int(bl[i, k])) for k in range(nb[i])]
+            assert got == want and int(oe[i]) == c["open_end"], c["name"]
+            assert got == O.gate_stream(caps[i], a_start, a_end, 16)[0]
+            for b in range(len(caps[i]) // 2048):
+                assert amp[i, b] == O.get_amplitude(caps[i][2048 * b: 2048 * b + 2048]), (c["name"], b)
+        r = afskmodem.Receiver(1200, a_start, a_end)
+        decoded = r.decode_captures(caps)
+        for c, payloads in zip(cases, decoded):
+            for p, b in zip(payloads, c["bursts"]):
+                if b["len"] == b["ref_len"]:
+                    assert p.hex() == b["bytes_hex"], c["name"]
+    # max_bursts clamps, ragged + tiny captures, seeded random captures against the oracle
+    rng = np.random.default_rng(8)
+    caps = [rng.integers(-32768, 32768, int(n)).astype(np.int16) * (rng.integers(0, 2, int(n)).astype(np.int16))
+            for n in (0, 100, 2048, 4096, 50000, 123457)]
+    caps += [np.concatenate([rng.integers(-a, a + 1, 2048 * int(k)).astype(np.int16)
+                             for a, k in zip(rng.integers(1000, 32000, 12), rng.integers(1, 4, 12))])
+             for _ in range(20)]
+    samples, off, ln, max_len = batch.upload_streams(caps)
+    for mb in (1, 3, 16):
+        g = batch.gate_batch(samples, off, ln, max_len, 18000, 14000, mb)
+        torch.cuda.synchronize()
+        nb, bs, bl, oe = (t.cpu().numpy() for t in (g.n_bursts, g.burst_start, g.burst_len, g.open_end))
+        for i, cap in enumerate(caps):
+            want, want_oe = O.gate_stream(cap, 18000, 14000, mb)
+            assert [(int(bs[i, k]), int(bl[i, k])) for k in range(nb[i])] == want, (i, mb)
+            assert int(oe[i]) == want_oe, (i, mb)

@@ -108,3 +108,18 @@ def test_demod_batch_matches_cases(golden):
 def test_readme_roundtrip(golden):
     w = O.wav_convert(O.get_frames("Héellóo World!".encode(), 1200))
     assert O.load_frames(w, 1200).decode("utf-8") == golden["readme_roundtrip"]
+
+
+def test_listen_gate_cases(golden):
+    """Receiver.__listen (ref:299-319) replayed over captures: burst boundaries as recorded from
+    the reference driven by a stub audio stream, and the decode of every closed burst."""
+    from tests.golden_inputs import build_capture
+    for c in golden["listen_cases"]:
+        cap = build_capture(c["recipe"])
+        assert len(cap) == c["n_samples"] and sha_i16(cap) == c["capture_sha256"], c["name"]
+        bursts, open_end = O.gate_stream(cap, c["amp_start"], c["amp_end"], 16)
+        assert open_end == c["open_end"], c["name"]
+        assert bursts == [(b["start"], b["len"]) for b in c["bursts"]], c["name"]
+        for (st, ln), b in zip(bursts, c["bursts"]):
+            if ln == b["ref_len"]:      # closed burst: identical frames went into the reference
+                assert O.load_frames(cap[st: st + ln], 1200, c["amp_end"]).hex() == b["bytes_hex"], c["name"]

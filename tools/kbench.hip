@@ -58,6 +58,23 @@ int main(int argc, char** argv) {
         printf("modulate_kernel: %.1f us per launch, %.2f TB/s written\n", ms / 5 * 1e3, 2.0 * n * L / (ms / 5 * 1e-3) / 1e12);
     }
 
+    {   // live-gate timing (block amplitudes + scan; read-bound, 2 B per sample)
+        const int mb = L / 2048, mbursts = 8;
+        int32_t *d_amp, *d_nb, *d_bs, *d_bl, *d_oe;
+        CK(hipMalloc(&d_amp, (size_t)n * mb * 4)); CK(hipMalloc(&d_nb, n * 4)); CK(hipMalloc(&d_oe, n * 4));
+        CK(hipMalloc(&d_bs, (size_t)n * mbursts * 4)); CK(hipMalloc(&d_bl, (size_t)n * mbursts * 4));
+        afsk::GateArgs g{d_x, d_off, d_len, 18000, 14000, n, mb, mbursts, d_amp, d_nb, d_bs, d_bl, d_oe};
+        CK(afsk::launch_gate(g, 0)); CK(hipDeviceSynchronize());
+        hipEvent_t m0, m1; CK(hipEventCreate(&m0)); CK(hipEventCreate(&m1));
+        CK(hipEventRecord(m0, 0));
+        for (int k = 0; k < 5; k++) CK(afsk::launch_gate(g, 0));
+        CK(hipEventRecord(m1, 0)); CK(hipEventSynchronize(m1));
+        float ms; CK(hipEventElapsedTime(&ms, m0, m1));
+        std::vector<int32_t> hn(n); CK(hipMemcpy(hn.data(), d_nb, n * 4, hipMemcpyDeviceToHost));
+        long tot = 0; for (int v : hn) tot += v;
+        printf("gate kernels: %.1f us per call, %.2f TB/s read (%ld bursts in %d captures)\n", ms / 5 * 1e3,
+               2.0 * n * (double)(mb * 2048) / (ms / 5 * 1e-3) / 1e12, tot, n);
+    }
     const int stride = 72;
     uint8_t* d_ob; int32_t* d_i32;
     CK(hipMalloc(&d_ob, (size_t)n * stride)); CK(hipMalloc(&d_i32, (size_t)n * 5 * 4));
