@@ -15,7 +15,9 @@ namespace afsk {
 
 constexpr int kListenBlock = 2048;   // ref:189, 209, 310
 
-struct __attribute__((packed, aligned(2))) vec16 { uint32_t v[4]; };
+// 16 bytes from a 2-byte-aligned address (gfx950 global loads are alignment-agnostic), read
+// with the non-temporal policy: every byte of a capture is read exactly once.
+typedef uint32_t vec16 __attribute__((ext_vector_type(4), aligned(2)));
 
 __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
     const int lane = threadIdx.x & 63;
@@ -29,12 +31,13 @@ __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
     uint32_t acc = 0;
     vec16 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const vec16*>(src + 512 * j + 8 * lane);
+    for (int j = 0; j < 4; j++)
+        v[j] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(src + 512 * j + 8 * lane));
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            acc = __builtin_amdgcn_sad_u16(v[j].v[k] ^ 0x80008000u, 0x80008000u, acc);   // sum |x|
+            acc = __builtin_amdgcn_sad_u16(v[j][k] ^ 0x80008000u, 0x80008000u, acc);   // sum |x|
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
     if (lane == 0) a.block_amp[(int64_t)s * a.max_blocks + b] = (int32_t)(acc >> 11);    // int(sum/2048)
