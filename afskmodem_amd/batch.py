@@ -263,6 +263,45 @@ def upload_streams(arrays, device="cuda:0"):
     return t(flat), t(offs), t(lens), int(lens.max()) if len(arrays) else 0
 
 
+def read_wav_frames(filename: str) -> np.ndarray:
+    """SoundInput.loadFromFile (ref:213-217) without the per-sample Python loop: every frame
+    byte of the file viewed as little-endian int16.  Like the reference, the header's rate,
+    width and channel count are NOT interpreted (a stereo or 8-bit file is read as if it were
+    mono 16-bit); an odd trailing byte is dropped (ref:201-205)."""
+    import wave
+    with wave.open(filename, "rb") as f:
+        raw = f.readframes(f.getnframes())
+    return np.frombuffer(raw, dtype="<i2", count=len(raw) // 2)
+
+
+def load_wav_batch(filenames, device="cuda:0", workers: int = 8):
+    """Many .wav files -> the stream-major device layout in one host->device copy.
+
+    Files are parsed in a thread pool (the reads release the GIL), packed back to back into
+    one pinned host buffer and uploaded once.  Returns (samples, stream_offset, stream_len,
+    max_len) like ``upload_streams``."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch = _torch()
+    names = list(filenames)
+    if not names:
+        return upload_streams([], device)
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(names)))) as ex:
+        arrays = list(ex.map(read_wav_frames, names))
+    lens = np.array([len(a) for a in arrays], dtype=np.int32)
+    offs = np.zeros(len(arrays), dtype=np.int64)
+    offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    total = int(lens.sum())
+    pin = torch.cuda.is_available() and str(device).startswith("cuda")
+    host = torch.empty(max(total, 1), dtype=torch.int16, pin_memory=pin)
+    hv = host.numpy()
+    for a, o in zip(arrays, offs):
+        hv[o: o + len(a)] = a
+    if total == 0:
+        hv[0] = 0
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return host.to(device, non_blocking=pin), t(offs), t(lens), int(lens.max())
+
+
 def modulate_batch(payload, payload_len, bit_frames, ts_cycles, stream_offset, stream_len,
                    max_stream_len: int, samples, wav_quirk: bool = True, stream=None) -> None:
     """On-device Transmitter.__getFrames + .wav quirk (ref:452-469, 239-244) into ``samples``.

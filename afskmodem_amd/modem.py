@@ -389,7 +389,20 @@ class Receiver:
         return out
 
     def load_batch(self, filenames, string: bool = False):
-        return self.decode_batch([SoundInput.loadArrayFromFile(f) for f in filenames], string)
+        """``load`` for many files: parallel .wav ingest into one device buffer
+        (``batch.load_wav_batch``), one demodulation launch."""
+        import torch
+        from . import batch
+        names = list(filenames)
+        if not names:
+            return []
+        samples, off, ln, max_len = batch.load_wav_batch(names)
+        self.check_decodable(max_len)
+        stride = batch.out_stride_for(max_len, self.__bit_frames)
+        res = batch.demod_batch(samples, off, ln, self.__bit_frames, self.__amp_end_threshold,
+                                out_stride=stride)
+        torch.cuda.synchronize()
+        return [d.decode("utf-8") if (string and d != b"") else d for d in res.payloads()]
 
     def decode_captures(self, captures, max_bursts: int = 16, string: bool = False):
         """What repeated ``receive()`` calls would return if each capture (a long int16

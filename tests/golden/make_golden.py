@@ -367,6 +367,21 @@ def main():
                                  "bursts": bursts, "open_end": open_end})
     G["listen_cases"] = listen_cases
 
+    # ---- 5c. .wav ingest (SoundInput.loadFromFile ref:213-217 is header-agnostic)
+    import wave
+    wav_cases = []
+    for name, (nch, width, rate, nbytes) in {"mono16": (1, 2, 48000, 9000), "stereo16": (2, 2, 44100, 8000),
+                                              "mono8_odd": (1, 1, 8000, 4001), "stereo24": (2, 3, 48000, 6006)}.items():
+        body = bytes(((i * 37 + 11) ^ (i >> 3)) & 0xFF for i in range(nbytes))
+        fn = os.path.join(tmpdir, name + ".wav")
+        with wave.open(fn, "wb") as f:
+            f.setnchannels(nch); f.setsampwidth(width); f.setframerate(rate)
+            f.writeframes(body)
+        got = ref.SoundInput.loadFromFile(fn)
+        wav_cases.append({"name": name, "nchannels": nch, "sampwidth": width, "framerate": rate,
+                          "nbytes": nbytes, "n_frames_ref": len(got), "frames_sha256": sha(got)})
+    G["wav_ingest"] = wav_cases
+
     # ---- 6. README assertion (README.md:47-66)
     fn = os.path.join(tmpdir, "afsk.wav")
     ref.Transmitter(1200).save("Héellóo World!", fn)

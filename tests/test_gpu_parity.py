@@ -356,3 +356,27 @@ def test_listen_gate_vs_reference_and_oracle(golden, torch_cuda):
             want, want_oe = O.gate_stream(cap, 18000, 14000, mb)
             assert [(int(bs[i, k]), int(bl[i, k])) for k in range(nb[i])] == want, (i, mb)
             assert int(oe[i]) == want_oe, (i, mb)
+
+
+def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
+    """Row f3: many .wav files -> one device buffer -> one launch == file-by-file Receiver.load."""
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    names, payloads = [], []
+    for i in range(40):
+        data = rng.integers(32, 127, int(rng.integers(0, 30)), dtype=np.uint8).tobytes()
+        fn = str(tmp_path / f"m{i}.wav")
+        afskmodem.Transmitter(1200, float(rng.choice([0.1, 0.2, 0.5]))).save(data, fn)
+        names.append(fn); payloads.append(data)
+    samples, off, ln, max_len = batch.load_wav_batch(names)
+    h = samples.cpu().numpy()
+    for i, fn in enumerate(names):
+        want = np.asarray(afskmodem.SoundInput.loadFromFile(fn), np.int16)
+        o = int(off[i]); assert np.array_equal(h[o: o + int(ln[i])], want), i
+    afskmodem.LOG_LEVEL = 5
+    r = afskmodem.Receiver(1200)
+    got = r.load_batch(names)
+    assert got == payloads
+    assert got == [r.load(fn, False) for fn in names]
+    assert r.load_batch(names[:3], string=True) == [p.decode() if p else b"" for p in payloads[:3]]
+    afskmodem.LOG_LEVEL = 0

@@ -207,3 +207,19 @@ def test_out_stride_never_truncates():
     for L, bf in ((48000, 20), (48000, 40), (48000, 160), (4096, 4), (10 ** 6, 8)):
         assert batch.out_stride_for(L, bf) >= L // (14 * bf) + 1
         assert batch.out_stride_for(L, bf) % 4 == 0
+
+
+def test_wav_ingest_is_header_agnostic_like_the_reference(golden, tmp_path):
+    """Row f3: batch.read_wav_frames == the reference's SoundInput.loadFromFile on files whose
+    headers say stereo / 8-bit / 24-bit / other rates (ref:213-217 ignores all of that)."""
+    import wave
+    for c in golden["wav_ingest"]:
+        body = bytes(((i * 37 + 11) ^ (i >> 3)) & 0xFF for i in range(c["nbytes"]))
+        fn = str(tmp_path / (c["name"] + ".wav"))
+        with wave.open(fn, "wb") as f:
+            f.setnchannels(c["nchannels"]); f.setsampwidth(c["sampwidth"]); f.setframerate(c["framerate"])
+            f.writeframes(body)
+        got = batch.read_wav_frames(fn)
+        assert len(got) == c["n_frames_ref"], c["name"]
+        assert sha_i16(got) == c["frames_sha256"], c["name"]
+        assert afskmodem.SoundInput.loadFromFile(fn) == got.tolist()
