@@ -380,3 +380,38 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
     assert got == [r.load(fn, False) for fn in names]
     assert r.load_batch(names[:3], string=True) == [p.decode() if p else b"" for p in payloads[:3]]
     afskmodem.LOG_LEVEL = 0
+
+
+def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
+    """The single-pass kernel re-aligns ring reads by (2*ci) & 15: exercise all 8 shifts, ring
+    wrap-around on long streams, and tiny symbol counts, for 300 / 1200 / 2400 baud."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    pieces, bfs = [], []
+    for baud in (300, 1200, 2400):
+        bf = 48000 // baud
+        t = afskmodem.Transmitter(baud, 0.1)
+        w_short = t.wav_samples(rng.integers(0, 256, 4, dtype=np.uint8).tobytes())
+        w_long = afskmodem.Transmitter(baud, 0.3).wav_samples(
+            rng.integers(0, 256, {300: 40, 1200: 160, 2400: 320}[baud], dtype=np.uint8).tobytes())
+        for lead in list(range(0, 9)) + [15, 16, 17, 511, 517, 1023, 2047, 3000]:
+            pieces.append(np.concatenate([rng.integers(-400, 400, lead).astype(np.int16), w_short]))
+            bfs.append(bf)
+        for lead in (0, 3, 5, 12):
+            pieces.append(np.concatenate([rng.integers(-400, 400, lead).astype(np.int16), w_long]))
+            bfs.append(bf)
+        # lengths hugging the 4096 window and the last-symbol rule (i < len - bf)
+        base = np.concatenate([np.zeros(5, np.int16), afskmodem.Transmitter(baud, 0.0).wav_samples(b"ok")])
+        base = np.concatenate([base, np.zeros(max(0, 4600 - len(base)), np.int16)])
+        for L in (4096, 4097, 4096 + bf - 1, 4096 + bf, 4096 + bf + 1, 4096 + 2 * bf, 4500, len(base)):
+            pieces.append(base[:L]); bfs.append(bf)
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    bf = np.array(bfs, np.int32)
+    flat = np.concatenate(pieces)
+    stride = 400
+    got = device_demod(torch, flat, off, ln, bf, stride=stride)
+    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=8)
+    assert_same(got, want, "alignment shifts")
+    assert len(set(int(c) & 7 for c in got.clock_idx)) == 8      # all 8 shifts were exercised
+    assert (got.nbytes > 100).any() and (got.nbits % 14 != 0).any()
