@@ -32,7 +32,7 @@ struct ModulateArgs {
     int32_t n_streams;
     int32_t wav_quirk;
     int16_t* samples;
-    int32_t chunks;   // 2048-sample chunks per stream (set by the launcher)
+    int32_t chunks;   // blocks per stream (set by the launcher)
 };
 
 struct NoiseArgs {

@@ -12,20 +12,17 @@
 
 namespace afsk {
 
-struct __attribute__((packed, aligned(2))) pack8 { int16_t v[8]; };
+struct pack8 { int16_t v[8]; };
+// 16 bytes to a 2-byte-aligned address with ONE global_store_dwordx4 (gfx950 stores are
+// alignment-agnostic; a packed struct made hipcc split the store in three).
+typedef uint32_t store16 __attribute__((ext_vector_type(4), aligned(2)));
 
-// ref:115-123: codeword p1 p2 d1 p3 d2 d3 d4 for nibble d1 d2 d3 d4 (d1 = MSB)
-__device__ __forceinline__ uint32_t hamming_encode_bit(uint32_t nib, int pos) {
-    const uint32_t d1 = (nib >> 3) & 1u, d2 = (nib >> 2) & 1u, d3 = (nib >> 1) & 1u, d4 = nib & 1u;
-    switch (pos) {
-        case 0: return d1 ^ d2 ^ d4;   // row 1101
-        case 1: return d1 ^ d3 ^ d4;   // row 1011
-        case 2: return d1;             // row 1000
-        case 3: return d2 ^ d3 ^ d4;   // row 0111
-        case 4: return d2;             // row 0100
-        case 5: return d3;             // row 0010
-        default: return d4;            // row 0001
-    }
+__device__ __forceinline__ void store_pack8(int16_t* dst, const pack8& v) {
+    store16 w;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        w[k] = (uint32_t)(uint16_t)v.v[2 * k] | ((uint32_t)(uint16_t)v.v[2 * k + 1] << 16);
+    *reinterpret_cast<store16*>(dst) = w;
 }
 
 // Symbol layout of the ideal frame list (ref:452-469), in symbols of bf frames:
@@ -33,91 +30,128 @@ __device__ __forceinline__ uint32_t hamming_encode_bit(uint32_t nib, int pos) {
 //   [2*ts, 2*ts + 4)     terminator: mark, space, space, space               ref:460-462
 //   [2*ts + 4, n_sym)    one symbol per Hamming-coded payload bit            ref:463-467
 // followed by 4800 zero frames (ref:468) and zero padding.
-struct SymbolMap {
-    uint32_t n_train_sym, n_sym;
-    const uint8_t* payload;
 
-    // true = mark tone, false = space tone, for symbol index S < n_sym
-    __device__ __forceinline__ bool is_mark(uint32_t S, uint32_t byte_lo, uint32_t byte_hi,
-                                            uint32_t first_byte) const {
-        if (S < n_train_sym) return (S & 1u) == 0;
-        const uint32_t t = S - n_train_sym;
-        if (t < 4) return t == 0;
-        const uint32_t b = t - 4;                  // coded bit index
-        const uint32_t cw = b / 7u;                // nibble index
-        const uint32_t pos = b - cw * 7u;
-        const uint32_t byte = ((cw >> 1) == first_byte) ? byte_lo : byte_hi;
-        const uint32_t nib = (cw & 1u) ? (byte & 15u) : (byte >> 4);   // ref:446-450 MSB first
-        return hamming_encode_bit(nib, (int)pos) != 0;
-    }
-};
+// Hamming(7,4) codeword of a nibble as a 7-bit integer, bit k = k-th transmitted bit
+// (p1 p2 d1 p3 d2 d3 d4; generator rows ref:115-123).
+__device__ __forceinline__ uint32_t hamming_codeword(uint32_t nib) {
+    const uint32_t d1 = (nib >> 3) & 1u, d2 = (nib >> 2) & 1u, d3 = (nib >> 1) & 1u, d4 = nib & 1u;
+    return (d1 ^ d2 ^ d4) | ((d1 ^ d3 ^ d4) << 1) | (d1 << 2) | ((d2 ^ d3 ^ d4) << 3) | (d2 << 4) |
+           (d3 << 5) | (d4 << 6);
+}
 
-// One thread = 8 consecutive output samples = one 16-byte store.  All positions fit in
-// 32 bits (stream_len < 2^30).  One integer division locates the first frame's symbol; the
-// thread touches at most 3 symbols (bf >= 4), whose tone kinds are resolved up front.
-__global__ __launch_bounds__(256) void modulate_kernel(ModulateArgs a) {
+constexpr int kModThreads = 256;
+constexpr int kModIters = 4;                                   // 16-byte stores per thread
+constexpr int kModChunk = kModThreads * 8 * kModIters;         // samples per block (8192)
+
+// Branch-free tone kind of symbol S (true = mark).  `win` is the block's payload window in
+// LDS: win[k] = payload[first_byte + k].
+__device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym, uint32_t first_byte,
+                                               const uint8_t* win) {
+    const uint32_t t = S - n_train_sym;              // wraps for training symbols (unused then)
+    const uint32_t b = t - 4u;                       // coded bit index (wraps before the data)
+    const uint32_t cw = b / 7u;                      // nibble index
+    const uint32_t pos = b - cw * 7u;
+    const uint32_t byte = win[((cw >> 1) - first_byte) & (kModThreads - 1)];
+    const uint32_t nib = (cw & 1u) ? (byte & 15u) : (byte >> 4);        // ref:446-450 MSB first
+    const bool data_bit = ((hamming_codeword(nib) >> pos) & 1u) != 0;
+    const bool train = S < n_train_sym;
+    const bool term = t < 4u;
+    return train ? ((S & 1u) == 0) : (term ? (t == 0u) : data_bit);
+}
+
+// One block = 8192 consecutive output samples of one stream; one thread = 4 x (8 samples =
+// one 16-byte store).  The per-stream scalars and the block's payload window (staged in LDS)
+// are fetched once per block, so the global-load latency is paid once per 16 KiB written.  All
+// positions fit in 32 bits (stream_len < 2^30).  Per store one integer division locates the
+// first frame's symbol; a store touches at most 3 symbols (bf >= 4); the per-sample part is
+// branch-free.
+__global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
+    __shared__ uint8_t win[kModThreads];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const uint32_t len = (uint32_t)a.stream_len[s];
-    const uint32_t p0 = ((uint32_t)chunk * blockDim.x + threadIdx.x) * 8u;
-    if (p0 >= len) return;
+    const uint32_t base = (uint32_t)chunk * kModChunk;
+    if (base >= len) return;                                   // block-uniform
     const uint32_t bf = (uint32_t)a.bit_frames[s];
     const uint32_t plen = (uint32_t)a.payload_len[s];
-    SymbolMap m;
-    m.n_train_sym = 2u * (uint32_t)a.ts_cycles[s];
-    m.n_sym = m.n_train_sym + 4u + 14u * plen;
-    m.payload = a.payload + (int64_t)s * a.payload_stride;
-    const uint64_t n_tones64 = (uint64_t)m.n_sym * bf;
+    const uint32_t n_train_sym = 2u * (uint32_t)a.ts_cycles[s];
+    const uint32_t n_sym = n_train_sym + 4u + 14u * plen;
+    const uint8_t* payload = a.payload + (int64_t)s * a.payload_stride;
+    const uint64_t n_tones64 = (uint64_t)n_sym * bf;
     const uint64_t n_frames64 = n_tones64 + 4800u;
     // wav quirk ref:239-244: out[2i] = out[2i+1] = frames[2i] for 2i < n_frames - 1
     const uint64_t n_out64 = a.wav_quirk ? (n_frames64 & ~1ull) : n_frames64;
     const uint32_t n_tones = n_tones64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_tones64;
     const uint32_t n_out = n_out64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_out64;
-    int16_t* dst = a.samples + a.stream_offset[s] + p0;
+    const uint32_t lim = n_tones < n_out ? n_tones : n_out;    // frames at or past this are zero
+    int16_t* dst0 = a.samples + a.stream_offset[s];
 
-    const uint32_t S0 = p0 / bf;
-    uint32_t ph = p0 - S0 * bf;
-    // payload bytes the (at most three) symbols S0..S0+2 can need
-    uint32_t first_byte = 0, byte_lo = 0, byte_hi = 0;
-    if (S0 + 2 >= m.n_train_sym + 4u && plen > 0) {
-        const uint32_t b0 = S0 > m.n_train_sym + 4u ? S0 - (m.n_train_sym + 4u) : 0u;
-        first_byte = (b0 / 7u) >> 1;
-        if (first_byte < plen) byte_lo = m.payload[first_byte];
-        if (first_byte + 1 < plen) byte_hi = m.payload[first_byte + 1];
+    // payload window of this block: the block spans < 8192 / (14 * bf) + 2 <= 148 bytes
+    const uint32_t data0 = n_train_sym + 4u;
+    const uint32_t Sb = base / bf;
+    const uint32_t first_byte = ((Sb > data0 ? Sb - data0 : 0u) / 7u) >> 1;
+    {
+        const uint32_t idx = first_byte + threadIdx.x;
+        win[threadIdx.x] = idx < plen ? payload[idx] : (uint8_t)0;
     }
-    bool kind[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-        kind[k] = (S0 + k < m.n_sym) ? m.is_mark(S0 + k, byte_lo, byte_hi, first_byte) : false;
+    __syncthreads();
 
-    const uint32_t step = a.wav_quirk ? 2u : 1u;
-    pack8 v;
-    uint32_t wraps = 0;
+    // Symbol / phase of this thread's first store, then advanced by 2048 samples per iteration
+    // without further divisions: x < bf + 2048 (bf < 2048), so a float estimate + fix-up is exact.
+    const uint32_t phb = base - Sb * bf;
+    const float rcp_bf = 1.0f / (float)bf;
+    auto divmod_small = [&](uint32_t x, uint32_t& q, uint32_t& r) {
+        q = (uint32_t)((float)x * rcp_bf);
+        int32_t rr = (int32_t)(x - q * bf);
+        if (rr < 0) { q -= 1; rr += (int32_t)bf; }
+        else if (rr >= (int32_t)bf) { q += 1; rr -= (int32_t)bf; }
+        r = (uint32_t)rr;
+    };
+    uint32_t dq, ph0;
+    divmod_small(phb + 8u * threadIdx.x, dq, ph0);
+    uint32_t S0 = Sb + dq;
+    uint32_t step_q, step_r;                                   // 2048 = step_q * bf + step_r
+    divmod_small(2048u, step_q, step_r);
+
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t p = p0 + j;
-        const bool fresh = a.wav_quirk ? ((j & 1) == 0) : true;   // odd outputs repeat the even frame
-        if (fresh) {
-            int16_t val = 0;
-            if (p < n_tones && p < n_out) {
-                const bool mark = wraps == 0 ? kind[0] : (wraps == 1 ? kind[1] : kind[2]);
-                const uint32_t ph4 = 4u * ph;
-                const bool hi_mark = (ph4 < bf) || (ph4 >= 2u * bf && ph4 < 3u * bf);   // ref:80-85
-                const bool hi_space = 2u * ph < bf;                                      // ref:68-77
-                val = (mark ? hi_mark : hi_space) ? (int16_t)32767 : (int16_t)-32768;
-            }
-            v.v[j] = val;
-            ph += step;
-            if (ph >= bf) { ph -= bf; wraps++; }
-            if (ph >= bf) { ph -= bf; wraps++; }   // step 2 with bf == ... keeps ph < bf (bf >= 4)
+    for (int it = 0; it < kModIters; it++) {
+        const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
+        if (p0 >= len) break;
+        const bool k0 = symbol_is_mark(S0, n_train_sym, first_byte, win);
+        const bool k1 = symbol_is_mark(S0 + 1u, n_train_sym, first_byte, win);
+        const bool k2 = symbol_is_mark(S0 + 2u, n_train_sym, first_byte, win);
+        // tone of the frame at offset dj from p0 (branch-free)
+        auto frame = [&](uint32_t dj) -> int16_t {
+            const uint32_t phj = ph0 + dj;                      // < bf + 7 < 3*bf
+            const uint32_t w = (uint32_t)(phj >= bf) + (uint32_t)(phj >= 2u * bf);
+            const uint32_t ph = phj - w * bf;
+            const bool mark = w == 0 ? k0 : (w == 1 ? k1 : k2);
+            const uint32_t ph4 = 4u * ph;
+            const bool hi_mark = (ph4 < bf) | ((ph4 >= 2u * bf) & (ph4 < 3u * bf));   // ref:80-85
+            const bool hi_space = 2u * ph < bf;                                          // ref:68-77
+            const int16_t tone = (mark ? hi_mark : hi_space) ? (int16_t)32767 : (int16_t)-32768;
+            return (p0 + dj) < lim ? tone : (int16_t)0;
+        };
+        pack8 v;
+        if (a.wav_quirk) {        // block-uniform: out[2i] = out[2i+1] = frames[2i] (ref:239-244)
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j += 2) v.v[j] = v.v[j + 1] = frame(j);
         } else {
-            v.v[j] = (p < n_out) ? v.v[j - 1] : (int16_t)0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v.v[j] = frame(j);
         }
-    }
-    if (p0 + 8u <= len) {
-        *reinterpret_cast<pack8*>(dst) = v;
-    } else {
-        for (uint32_t j = 0; j < 8u && p0 + j < len; j++) dst[j] = v.v[j];
+        int16_t* dst = dst0 + p0;
+        if (p0 + 8u <= len) {
+            store_pack8(dst, v);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++)
+                if (p0 + j < len) dst[j] = v.v[j];
+        }
+        // next store of this thread is 2048 samples further
+        S0 += step_q;
+        ph0 += step_r;
+        if (ph0 >= bf) { ph0 -= bf; S0 += 1u; }
     }
 }
 
@@ -153,11 +187,11 @@ __global__ __launch_bounds__(256) void noise_kernel(NoiseArgs a) {
 
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream) {
     if (a.n_streams <= 0 || max_len <= 0) return hipSuccess;
-    const int per_block = 256 * 8;
+    const int per_block = kModChunk;
     a.chunks = (max_len + per_block - 1) / per_block;
     const int64_t blocks = (int64_t)a.chunks * a.n_streams;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(modulate_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(modulate_kernel, dim3((uint32_t)blocks), dim3(kModThreads), 0, stream, a);
     return hipGetLastError();
 }
 
