@@ -7,11 +7,12 @@
 //
 //   ring      16 x 1 KiB chunks; chunk c (samples 512c .. 512c+511) lives in slot
 //             c & 15; one `buffer_load_dwordx4 ... lds` per chunk, bounds-checked by
-//             a descriptor over the whole stream (tail reads return 0).
+//             a descriptor over the whole stream (tail reads return 0).  Chunks 0..11
+//             are requested at once; slots 12..15 hold phase A's prefix window first.
 //   phase A   ref:322-339 on the first 8 chunks as they land (progressive vmcnt):
-//             a producer turns 128 raw samples per step into exclusive prefix sums
-//             (DPP wave scan) kept in a 512-entry circular window; the consumer
-//             evaluates 64 sync offsets per step with 7 window reads each.
+//             a producer turns 256 raw samples per step into exclusive prefix sums
+//             (DPP wave scan) kept in a 512/1024-entry circular window; a consumer
+//             step evaluates 256 (128 at 300 baud) sync offsets, 7 window reads each.
 //   phase B   ref:342-351: every lane owns an 80-byte piece (40 samples: one
 //             1200-baud symbol, two 2400-baud symbols, a quarter 300-baud symbol) at
 //             ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as six aligned
@@ -72,74 +73,97 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// Geometry of the circular prefix-sum window for one baud rate.  The window holds PW
-// entries; its first MIRROR entries are stored a second time at [PW, PW + MIRROR) so that a
-// consumer can read P[i + e] at (i mod PW) + e without wrapping: every LDS address of the
-// search is then `lane*4 + immediate`.
+// Geometry of the clock search for one baud rate.  Prefix sums live in a circular window
+// of PW int32 entries that occupies ring slots 12..15 while phase A runs (those chunks are
+// requested only afterwards).  A producer step turns 256 raw samples (4 per lane) into prefix
+// sums; a consumer step evaluates OC = 64*GC sync offsets (GC per lane), so the LDS round trip
+// of its 7*GC window reads is paid once per OC offsets -- phase A is latency-bound, not
+// throughput-bound, and this is what makes it short.
 template <int BF>
 struct SyncGeom {
     static constexpr int N = 2 * BF;
-    static constexpr int PW = (N + 192 <= 256) ? 256 : 512;
-    static constexpr int MIRROR = ((N + 64 + 127) / 128) * 128;
-    static constexpr int ENTRIES = PW + MIRROR;
-    static_assert(N + 192 <= PW, "prefix window too small for this baud");
+    static constexpr int GC = BF <= 64 ? 4 : 2;                // offsets per lane per consumer step
+    static constexpr int OC = 64 * GC;
+    static constexpr int PW = BF <= 64 ? 512 : 1024;           // window entries (2 or 4 producer steps)
+    static constexpr int NOFF = kSync - N;                     // ref:327
+    static constexpr int T = (NOFF + OC - 1) / OC;             // consumer steps
+    static constexpr int PSTEPS = kSync / 256;                 // 16 producer steps
+    // producer steps that must be complete before consumer step t
+    static constexpr int done_before(int t) {
+        if (t < 0) return 0;
+        const int need = (OC * t + OC - 1 + N) / 256 + 1;
+        return need > PSTEPS ? PSTEPS : need;
+    }
+    // the newest step produced for consumer t must not overwrite the oldest one it still reads
+    static constexpr bool window_ok() {
+        for (int t = 0; t < T; t++)
+            if (done_before(t) - 1 - PW / 256 >= (OC * t) / 256) return false;
+        return true;
+    }
+    static_assert(PW * 4 <= 4096, "window must fit ring slots 12..15");
 };
-constexpr int kPWinMaxBytes = SyncGeom<160>::ENTRIES * 4;      // 3.5 KiB (largest of 20/40/160)
-constexpr int kFastWaveLds = kRingBytes + kPWinMaxBytes;
+constexpr int kSyncChunks = 12;                                // chunks requested before phase A
+constexpr int kPWinOffset = kSyncChunks * 1024;                // window = ring bytes [12 KiB, 16 KiB)
+constexpr int kFastWaveLds = kRingBytes;
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
                                                         uint32_t* dbg = nullptr) {
     using G = SyncGeom<BF>;
-    constexpr int N = G::N, Q = BF / 4, H = BF / 2, PW = G::PW;
-    constexpr int NOFF = kSync - N;                       // ref:327
-    constexpr int T = (NOFF + 63) / 64;                   // consumer steps of 64 offsets
+    constexpr int N = G::N, Q = BF / 4, H = BF / 2, PW = G::PW, GC = G::GC, OC = G::OC;
+    constexpr int NOFF = G::NOFF;
+    static_assert(G::window_ok(), "prefix window too small for this baud");
     constexpr uint32_t C = 65535u * (uint32_t)BF;
     // floor(total / N) for total < 2^27 as mul_hi(total, M) >> 4 with M = ceil(2^36 / N):
     // error term total * (M*N - 2^36) < 2^27 * N <= 2^36 for N <= 512.
     constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
     static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
     const int lane = fr.lane;
-    const uint32_t* raw = reinterpret_cast<const uint32_t*>(fr.ring);
     int32_t carry = 0;
     uint32_t best = 0xFFFFFFFFu;
-    // producer steps (128 samples each) that must be complete before consumer step t
-    auto done_before = [](int t) constexpr { return t < 0 ? 0 : ((64 * t + 63 + N) / 128 + 1 > 32 ? 32 : (64 * t + 63 + N) / 128 + 1); };
-    static_for<0, T>([&](auto tc) {
+    static_for<0, G::T>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        constexpr int u0 = done_before(t - 1), u1 = done_before(t);
+        constexpr int u0 = G::done_before(t - 1), u1 = G::done_before(t);
         static_for<u0, u1>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            if constexpr ((u & 3) == 0) wait_vmcnt<15 - u / 4>();        // chunk u/4 has landed
-            const uint32_t w = raw[64 * u + lane];
-            const int32_t x0 = ((int32_t)(w << 16)) >> 16, x1 = ((int32_t)w) >> 16;
-            const int32_t s = x0 + x1;
-            const int32_t incl = wave_incl_scan_dpp(s);
-            const int32_t base = carry + incl - s;
-            constexpr int j0 = (128 * u) & (PW - 1);
-            int32_t* dst = pw + j0 + 2 * lane;
-            dst[0] = base;                                // P[128u + 2*lane]
-            dst[1] = base + x0;                           // P[128u + 2*lane + 1]
-            if constexpr (j0 < G::MIRROR) {
-                dst[PW] = base;
-                dst[PW + 1] = base + x0;
-            }
+            if constexpr ((u & 1) == 0) wait_vmcnt<kSyncChunks - 1 - u / 2>();   // chunk u/2 has landed
+            const u32x2 w = *reinterpret_cast<const u32x2*>(fr.ring + 512 * u + 8 * lane);
+            const int32_t x0 = ((int32_t)(w[0] << 16)) >> 16, x1 = ((int32_t)w[0]) >> 16;
+            const int32_t x2 = ((int32_t)(w[1] << 16)) >> 16, x3 = ((int32_t)w[1]) >> 16;
+            const int32_t e1 = x0, e2 = x0 + x1, e3 = e2 + x2, tot = e3 + x3;
+            const int32_t incl = wave_incl_scan_dpp(tot);
+            const int32_t base = carry + incl - tot;
+            constexpr int j0 = (256 * u) % PW;
+            const u32x4 pv = {(uint32_t)base, (uint32_t)(base + e1), (uint32_t)(base + e2),
+                              (uint32_t)(base + e3)};            // P[256u + 4*lane + 0..3]
+            *reinterpret_cast<u32x4*>(pw + j0 + 4 * lane) = pv;
             carry += __builtin_amdgcn_readlane(incl, 63);
         });
         if constexpr (u1 > u0) wave_lds_sync();           // other lanes read these stores
-        // consumer: total(i) = sum_j |tc[j] - x[i+j]| for i = 64t + lane (see afsk_demod_impl.h)
-        constexpr int b0 = (64 * t) & (PW - 1);
-        const int32_t* p = pw + b0 + lane;
-        const int32_t tt = p[0] + p[N] + 2 * (p[2 * Q] + p[BF] - p[Q] - p[3 * Q] - p[BF + H]);
-        const uint32_t total = C + (uint32_t)tt;
-        const uint32_t mean = __umulhi(total, M) >> 4;    // ref:107, exact integer division
-        const uint32_t key = (mean << 12) | (uint32_t)(64 * t + lane);
-        if constexpr (DEBUG) dbg[64 * t + lane] = total;
-        if constexpr (64 * t + 63 < NOFF) {
-            best = key < best ? key : best;               // strict <, first minimum: ref:332-337
-        } else {
-            if (64 * t + lane < NOFF && key < best) best = key;
-        }
+        // consumer: total(i) = sum_j |tc[j] - x[i+j]| for i = OC*t + 64*g + lane
+        uint32_t key[GC];
+        static_for<0, GC>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int i0 = OC * t + 64 * g;           // offset of lane 0
+            auto P = [&](auto ec) -> int32_t {
+                constexpr int c = (i0 + decltype(ec)::value) % PW;
+                if constexpr (c + 63 < PW) return pw[c + lane];                 // lane*4 + immediate
+                else return pw[(c + lane) & (PW - 1)];                           // wraps inside the wave
+            };
+            using std::integral_constant;
+            const int32_t tt = P(integral_constant<int, 0>{}) + P(integral_constant<int, N>{}) +
+                               2 * (P(integral_constant<int, 2 * Q>{}) + P(integral_constant<int, BF>{}) -
+                                    P(integral_constant<int, Q>{}) - P(integral_constant<int, 3 * Q>{}) -
+                                    P(integral_constant<int, BF + H>{}));
+            const uint32_t total = C + (uint32_t)tt;
+            const uint32_t mean = __umulhi(total, M) >> 4;    // ref:107, exact integer division
+            if constexpr (DEBUG) dbg[i0 + lane] = total;
+            uint32_t k = (mean << 12) | (uint32_t)(i0 + lane);
+            if constexpr (i0 + 63 >= NOFF) k = (i0 + lane < NOFF) ? k : 0xFFFFFFFFu;
+            key[g] = k;
+        });
+#pragma unroll
+        for (int g = 0; g < GC; g++) best = key[g] < best ? key[g] : best;   // first minimum: ref:332-337
     });
     best = wave_min_u32(best);
     return (int)(__builtin_amdgcn_readfirstlane(best) & 4095u);
@@ -331,24 +355,28 @@ template <int BF, int FLAGS>
 __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
                                                   uint8_t* lds, int lane, RxState& st,
                                                   uint8_t* out_row, int out_stride, int& ci_out,
-                                                  int32_t& n_sym_out) {
+                                                  int32_t& n_sym_out,
+                                                  unsigned long long* stamps = nullptr) {
     constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
     fr.lane = lane;
 #pragma unroll
-    for (int c = 0; c < kRingChunks; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
-    fr.next = kRingChunks;
+    for (int c = 0; c < kSyncChunks; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
+    fr.next = kSyncChunks;                                  // slots 12..15 hold the prefix window
 
     int ci = 0;
     if constexpr (FLAGS & 1) {
-        wait_vmcnt<8>();
+        wait_vmcnt<kSyncChunks - 8>();
     } else {
-        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kRingBytes));
+        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kPWinOffset));
     }
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (FLAGS & 64) {
+        if (lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     const int32_t rel_len = len - ci;
     const int32_t K = (rel_len - 1) / BF;                      // symbols with i < len - bf (ref:362,372)

@@ -497,9 +497,12 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     if (FAST && (bf == 40 || bf == 20 || bf == 160)) {
         if constexpr (FAST) {
             switch (bf) {
-                case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym); break;
-                case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym); break;
-                default:  demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym); break;
+                case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
+                                                       (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
+                case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
+                                                       (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
+                default:  demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
+                                                        (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
             }
         }
     } else {
@@ -536,8 +539,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void demod_kernel_t(DemodArgs 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = blockIdx.x * kWavesPerBlock + wave;
     if (s >= a.n_streams) return;
+    if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
+        if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();
+    }
     process_stream<FLAGS, FAST>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
-                                      lds_all + wave * kLdsPerWave, lane);
+                                lds_all + wave * kLdsPerWave, lane);
+    if constexpr (FLAGS & 64) {
+        if (lane == 0) a.debug_stamps[4 * s + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 }  // namespace afsk

@@ -19,6 +19,7 @@ struct DemodArgs {
     int32_t* out_clock_idx;
     int32_t* out_term_frame;
     int32_t* out_status;
+    unsigned long long* debug_stamps = nullptr;   // diagnostics only (tools/kbench): 4 x u64 per stream
 };
 
 struct ModulateArgs {

@@ -88,6 +88,26 @@ int main(int argc, char** argv) {
         {"v2 skip_valu", launch_flags<2, true>, false},
         {"v2 skip_sync+valu", launch_flags<3, true>, false},
     };
+    {   // timeline of one launch of the diagnostic (stamped) build
+        unsigned long long* d_st; CK(hipMalloc(&d_st, (size_t)n * 32)); CK(hipMemset(d_st, 0, (size_t)n * 32));
+        DemodArgs as = a; as.debug_stamps = d_st;
+        for (int rep = 0; rep < 3; rep++) { launch_flags<64, true>(as, 0); CK(hipDeviceSynchronize()); }
+        std::vector<unsigned long long> st((size_t)n * 4);
+        CK(hipMemcpy(st.data(), d_st, (size_t)n * 32, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull; for (int s = 0; s < n; s++) t0 = std::min(t0, st[4 * s]);
+        auto pct = [&](int field, double p) { std::vector<double> v(n); for (int s = 0; s < n; s++) v[s] = (st[4 * s + field] - t0) * 0.01; std::sort(v.begin(), v.end()); return v[(size_t)(p * (n - 1))]; };
+        printf("timeline (us since first wave start; min / median / p90 / max over %d streams)\n", n);
+        const char* names[4] = {"wave start", "sync done ", "(unused)  ", "wave end  "};
+        for (int f : {0, 1, 3}) printf("  %s %7.2f %7.2f %7.2f %7.2f\n", names[f], pct(f, 0), pct(f, 0.5), pct(f, 0.9), pct(f, 1.0));
+        std::vector<double> d1(n), d2(n); for (int s = 0; s < n; s++) { d1[s] = (st[4 * s + 1] - st[4 * s]) * 0.01; d2[s] = (st[4 * s + 3] - st[4 * s + 1]) * 0.01; }
+        std::sort(d1.begin(), d1.end()); std::sort(d2.begin(), d2.end());
+        printf("  per-wave: start->sync done median %.2f us (p10 %.2f, p90 %.2f); sync done->end median %.2f us (p10 %.2f, p90 %.2f)\n",
+               d1[n / 2], d1[n / 10], d1[9 * n / 10], d2[n / 2], d2[n / 10], d2[9 * n / 10]);
+        // generation split: streams in first half of block ids vs second half
+        int late = 0; for (int s = 0; s < n; s++) late += ((st[4 * s] - t0) * 0.01 > 10.0);
+        printf("  waves starting later than 10 us after launch: %d of %d\n", late, n);
+        CK(hipFree(d_st));
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> times(vs.size());
     // reference outputs from variant 0
