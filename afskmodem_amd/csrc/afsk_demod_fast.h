@@ -100,7 +100,10 @@ struct SyncGeom {
             if (done_before(t) - 1 - PW / 256 >= (OC * t) / 256) return false;
         return true;
     }
-    static_assert(PW * 4 <= 4096, "window must fit ring slots 12..15");
+    // BF <= 64: the first N entries of every even producer step are stored a second time past
+    // the end of the window, so a consumer's reads never wrap and need no address masking.
+    static constexpr int MIRROR = BF <= 64 ? ((N + 3) / 4) * 4 : 0;
+    static_assert((PW + MIRROR) * 4 <= 4096, "window must fit ring slots 12..15");
 };
 constexpr int kSyncChunks = 12;                                // chunks requested before phase A
 constexpr int kPWinOffset = kSyncChunks * 1024;                // window = ring bytes [12 KiB, 16 KiB)
@@ -108,65 +111,135 @@ constexpr int kFastWaveLds = kRingBytes;
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
-                                                        uint32_t* dbg = nullptr) {
+                                                        uint32_t* dbg = nullptr,
+                                                        unsigned long long* stamps = nullptr) {
     using G = SyncGeom<BF>;
     constexpr int N = G::N, Q = BF / 4, H = BF / 2, PW = G::PW, GC = G::GC, OC = G::OC;
-    constexpr int NOFF = G::NOFF;
+    constexpr int NOFF = G::NOFF, T = G::T;
     static_assert(G::window_ok(), "prefix window too small for this baud");
     constexpr uint32_t C = 65535u * (uint32_t)BF;
-    // floor(total / N) for total < 2^27 as mul_hi(total, M) >> 4 with M = ceil(2^36 / N):
-    // error term total * (M*N - 2^36) < 2^27 * N <= 2^36 for N <= 512.
+    // floor(m / N) for m < 2^27 as mul_hi(m, M) >> 4 with M = ceil(2^36 / N):
+    // error term m * (M*N - 2^36) < 2^27 * N <= 2^36 for N <= 512.
     constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
     static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
     const int lane = fr.lane;
+    using std::integral_constant;
+
+    // ---- producer: 256 raw samples (4 per lane) -> 256 exclusive prefix sums in the window
     int32_t carry = 0;
-    uint32_t best = 0xFFFFFFFFu;
-    static_for<0, G::T>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int u0 = G::done_before(t - 1), u1 = G::done_before(t);
-        static_for<u0, u1>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
+    u32x2 raw_next;
+    auto load_raw = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u < G::PSTEPS) {
             if constexpr ((u & 1) == 0) wait_vmcnt<kSyncChunks - 1 - u / 2>();   // chunk u/2 has landed
-            const u32x2 w = *reinterpret_cast<const u32x2*>(fr.ring + 512 * u + 8 * lane);
-            const int32_t x0 = ((int32_t)(w[0] << 16)) >> 16, x1 = ((int32_t)w[0]) >> 16;
-            const int32_t x2 = ((int32_t)(w[1] << 16)) >> 16, x3 = ((int32_t)w[1]) >> 16;
-            const int32_t e1 = x0, e2 = x0 + x1, e3 = e2 + x2, tot = e3 + x3;
-            const int32_t incl = wave_incl_scan_dpp(tot);
-            const int32_t base = carry + incl - tot;
-            constexpr int j0 = (256 * u) % PW;
-            const u32x4 pv = {(uint32_t)base, (uint32_t)(base + e1), (uint32_t)(base + e2),
-                              (uint32_t)(base + e3)};            // P[256u + 4*lane + 0..3]
-            *reinterpret_cast<u32x4*>(pw + j0 + 4 * lane) = pv;
-            carry += __builtin_amdgcn_readlane(incl, 63);
-        });
-        if constexpr (u1 > u0) wave_lds_sync();           // other lanes read these stores
-        // consumer: total(i) = sum_j |tc[j] - x[i+j]| for i = OC*t + 64*g + lane
-        uint32_t key[GC];
-        static_for<0, GC>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int i0 = OC * t + 64 * g;           // offset of lane 0
-            auto P = [&](auto ec) -> int32_t {
-                constexpr int c = (i0 + decltype(ec)::value) % PW;
-                if constexpr (c + 63 < PW) return pw[c + lane];                 // lane*4 + immediate
-                else return pw[(c + lane) & (PW - 1)];                           // wraps inside the wave
-            };
-            using std::integral_constant;
-            const int32_t tt = P(integral_constant<int, 0>{}) + P(integral_constant<int, N>{}) +
-                               2 * (P(integral_constant<int, 2 * Q>{}) + P(integral_constant<int, BF>{}) -
-                                    P(integral_constant<int, Q>{}) - P(integral_constant<int, 3 * Q>{}) -
-                                    P(integral_constant<int, BF + H>{}));
-            const uint32_t total = C + (uint32_t)tt;
-            const uint32_t mean = __umulhi(total, M) >> 4;    // ref:107, exact integer division
-            if constexpr (DEBUG) dbg[i0 + lane] = total;
-            uint32_t k = (mean << 12) | (uint32_t)(i0 + lane);
-            if constexpr (i0 + 63 >= NOFF) k = (i0 + lane < NOFF) ? k : 0xFFFFFFFFu;
-            key[g] = k;
-        });
+            if constexpr (u == 0) { if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime(); }
+            raw_next = *reinterpret_cast<const u32x2*>(fr.ring + 512 * u + 8 * lane);
+        }
+    };
+    auto produce = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const u32x2 w = raw_next;
+        load_raw(integral_constant<int, u + 1>{});          // prefetch the next step's samples
+        const int32_t x0 = ((int32_t)(w[0] << 16)) >> 16, x1 = ((int32_t)w[0]) >> 16;
+        const int32_t x2 = ((int32_t)(w[1] << 16)) >> 16, x3 = ((int32_t)w[1]) >> 16;
+        const int32_t e1 = x0, e2 = x0 + x1, e3 = e2 + x2, tot = e3 + x3;
+        const int32_t incl = wave_incl_scan_dpp(tot);
+        const int32_t base = carry + incl - tot;
+        constexpr int j0 = (256 * u) % PW;
+        const u32x4 pv = {(uint32_t)base, (uint32_t)(base + e1), (uint32_t)(base + e2),
+                          (uint32_t)(base + e3)};                // P[256u + 4*lane + 0..3]
+        *reinterpret_cast<u32x4*>(pw + j0 + 4 * lane) = pv;
+        if constexpr (G::MIRROR > 0 && j0 == 0) {
+            if (4 * lane < G::MIRROR) *reinterpret_cast<u32x4*>(pw + PW + 4 * lane) = pv;
+        }
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    };
+
+    // ---- consumer: total(i) = sum_j |tc[j] - x[i+j]| for the GC CONSECUTIVE offsets
+    // i = OC*t + GC*lane + k of each lane, so one wide LDS read fetches P[i+e .. i+e+GC-1].
+    // Pass 1 keeps every total in registers and tracks the minimum; the first offset whose
+    // truncated mean equals the minimal one is found in pass 2 without a division per offset.
+    uint32_t totals[T * GC];
+    uint32_t min_total = 0xFFFFFFFFu;
+    int lane_t = lane;     // address seed of the window reads, re-defined after every step (below)
+    auto load_span = [&](auto cc, int32_t (&v)[GC]) {
+        constexpr int c = decltype(cc)::value;                // window entry of lane 0's first offset
+        constexpr bool wraps = c + 64 * GC > PW + G::MIRROR;  // some lane would run past the window
+        const int32_t* p = wraps ? pw + ((c + GC * lane_t) & (PW - 1)) : pw + c + GC * lane_t;
+        if constexpr (GC == 4 && c % 4 == 0) {
+            const u32x4 q4 = *reinterpret_cast<const u32x4*>(p);
+            v[0] = (int32_t)q4[0]; v[1] = (int32_t)q4[1]; v[2] = (int32_t)q4[2]; v[3] = (int32_t)q4[3];
+        } else if constexpr (c % 2 == 0) {
 #pragma unroll
-        for (int g = 0; g < GC; g++) best = key[g] < best ? key[g] : best;   // first minimum: ref:332-337
+            for (int k = 0; k < GC; k += 2) {
+                const u32x2 q2 = *reinterpret_cast<const u32x2*>(p + k);
+                v[k] = (int32_t)q2[0]; v[k + 1] = (int32_t)q2[1];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < GC; k++) v[k] = p[k];
+        }
+    };
+    static_assert(PW % GC == 0 && (BF > 64 || G::MIRROR >= N), "span reads must not straddle the wrap");
+
+    load_raw(integral_constant<int, 0>{});
+    static_for<0, G::done_before(0)>([&](auto uc) { produce(uc); });
+    wave_lds_sync();                                         // other lanes read these stores
+    static_for<0, T>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int cb = (OC * t) % PW;
+        // (1) issue this step's window reads
+        int32_t r[7][GC];
+        load_span(integral_constant<int, (cb + 0) % PW>{}, r[0]);
+        load_span(integral_constant<int, (cb + Q) % PW>{}, r[1]);
+        load_span(integral_constant<int, (cb + 2 * Q) % PW>{}, r[2]);
+        load_span(integral_constant<int, (cb + 3 * Q) % PW>{}, r[3]);
+        load_span(integral_constant<int, (cb + BF) % PW>{}, r[4]);
+        load_span(integral_constant<int, (cb + BF + H) % PW>{}, r[5]);
+        load_span(integral_constant<int, (cb + N) % PW>{}, r[6]);
+        // (2) while they are in flight, produce what the NEXT consumer step needs.  LDS executes
+        //     a wave's operations in order, so the reads above still see the old window content
+        //     -- provided the compiler keeps them above the stores below: per thread they do not
+        //     alias, so only a fence pins that order.
+        constexpr int u0 = G::done_before(t), u1 = G::done_before(t + 1);
+        if constexpr (t + 1 < T && u1 > u0) wave_lds_sync();
+        if constexpr (t + 1 < T) {
+            static_for<u0, u1>([&](auto uc) { produce(uc); });
+            if constexpr (u1 > u0) wave_lds_sync();
+        }
+        // (3) arithmetic of this step
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+            const int32_t tt = r[0][k] + r[6][k] + 2 * (r[2][k] + r[4][k] - r[1][k] - r[3][k] - r[5][k]);
+            uint32_t total = C + (uint32_t)tt;
+            const int i = OC * t + GC * lane + k;
+            if constexpr (DEBUG) dbg[i] = total;
+            if constexpr (OC * t + OC - 1 >= NOFF) total = (i < NOFF) ? total : 0xFFFFFFFFu;
+            totals[t * GC + k] = total;
+            min_total = total < min_total ? total : min_total;
+        }
+        // Tie the next step's read addresses to this step's result: without it hipcc issues the
+        // window reads of many steps ahead and parks them in registers (256 VGPR + 130 AGPR,
+        // one wave per SIMD instead of two).
+        {
+            int lt = lane_t;
+            uint32_t mt = min_total;
+            asm volatile("" : "+v"(lt), "+v"(mt));
+            lane_t = lt;
+            min_total = mt;
+        }
     });
-    best = wave_min_u32(best);
-    return (int)(__builtin_amdgcn_readfirstlane(best) & 4095u);
+    // ---- pass 2: first index whose mean int(total / N) is minimal (strict <, ref:332-337)
+    const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
+    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
+    uint32_t cand = 0xFFFFFFFFu;
+    static_for<0, T * GC>([&](auto kc) {
+        constexpr int k = T * GC - 1 - decltype(kc)::value;                // last to first: first wins
+        constexpr int i0 = OC * (k / GC) + (k % GC);                       // offset of lane 0
+        cand = totals[k] < bound ? (uint32_t)(i0 + GC * lane) : cand;
+    });
+    cand = wave_min_u32(cand);
+    return (int)__builtin_amdgcn_readfirstlane(cand);
 }
 
 // ------------------------------------------------------------------ phase B (fast)
@@ -370,7 +443,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     if constexpr (FLAGS & 1) {
         wait_vmcnt<kSyncChunks - 8>();
     } else {
-        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kPWinOffset));
+        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kPWinOffset), nullptr,
+                                          (FLAGS & 64) ? stamps : nullptr);
     }
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

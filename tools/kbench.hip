@@ -97,10 +97,11 @@ int main(int argc, char** argv) {
         unsigned long long t0 = ~0ull; for (int s = 0; s < n; s++) t0 = std::min(t0, st[4 * s]);
         auto pct = [&](int field, double p) { std::vector<double> v(n); for (int s = 0; s < n; s++) v[s] = (st[4 * s + field] - t0) * 0.01; std::sort(v.begin(), v.end()); return v[(size_t)(p * (n - 1))]; };
         printf("timeline (us since first wave start; min / median / p90 / max over %d streams)\n", n);
-        const char* names[4] = {"wave start", "sync done ", "(unused)  ", "wave end  "};
-        for (int f : {0, 1, 3}) printf("  %s %7.2f %7.2f %7.2f %7.2f\n", names[f], pct(f, 0), pct(f, 0.5), pct(f, 0.9), pct(f, 1.0));
-        std::vector<double> d1(n), d2(n); for (int s = 0; s < n; s++) { d1[s] = (st[4 * s + 1] - st[4 * s]) * 0.01; d2[s] = (st[4 * s + 3] - st[4 * s + 1]) * 0.01; }
-        std::sort(d1.begin(), d1.end()); std::sort(d2.begin(), d2.end());
+        const char* names[4] = {"wave start", "sync done ", "chunk0 in ", "wave end  "};
+        for (int f : {0, 2, 1, 3}) printf("  %s %7.2f %7.2f %7.2f %7.2f\n", names[f], pct(f, 0), pct(f, 0.5), pct(f, 0.9), pct(f, 1.0));
+        std::vector<double> d0(n), d1(n), d2(n); for (int s = 0; s < n; s++) { d0[s] = (st[4 * s + 2] - st[4 * s]) * 0.01; d1[s] = (st[4 * s + 1] - st[4 * s]) * 0.01; d2[s] = (st[4 * s + 3] - st[4 * s + 1]) * 0.01; }
+        std::sort(d0.begin(), d0.end()); std::sort(d1.begin(), d1.end()); std::sort(d2.begin(), d2.end());
+        printf("  per-wave: start->first chunk landed median %.2f us (p10 %.2f, p90 %.2f)\n", d0[n / 2], d0[n / 10], d0[9 * n / 10]);
         printf("  per-wave: start->sync done median %.2f us (p10 %.2f, p90 %.2f); sync done->end median %.2f us (p10 %.2f, p90 %.2f)\n",
                d1[n / 2], d1[n / 10], d1[9 * n / 10], d2[n / 2], d2[n / 10], d2[9 * n / 10]);
         // generation split: streams in first half of block ids vs second half
