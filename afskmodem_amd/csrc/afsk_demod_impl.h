@@ -531,13 +531,16 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
 // One wave per stream, one block per 4 streams; the hardware dispatcher balances blocks over
 // the CUs (a persistent grid with static striding measured 5 % slower at 65536 streams and
 // no faster at 4096, so it is not used).
-template <int FLAGS, bool FAST = true>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void demod_kernel_t(DemodArgs a) {
-    constexpr int kLdsPerWave = KernelCfg<FLAGS, FAST>::kLdsPerWave;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kLdsPerWave];
+// WPB = waves (= streams) per block; LDS_PER_WAVE >= 16 KiB sets how many blocks fit a CU's
+// 160 KiB LDS, i.e. the number of resident waves per CU.
+template <int FLAGS, bool FAST = true, int WPB = kWavesPerBlock, int LDS_PER_WAVE = 0>
+__global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
+    constexpr int kLdsPerWave = LDS_PER_WAVE > 0 ? LDS_PER_WAVE : KernelCfg<FLAGS, FAST>::kLdsPerWave;
+    static_assert(kLdsPerWave >= KernelCfg<FLAGS, FAST>::kLdsPerWave, "LDS per wave too small");
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kLdsPerWave];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = blockIdx.x * kWavesPerBlock + wave;
+    const int s = blockIdx.x * WPB + wave;
     if (s >= a.n_streams) return;
     if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
         if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();

@@ -23,6 +23,12 @@ static void launch_flags(const DemodArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((afsk::demod_kernel_t<FLAGS, FAST>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
 }
 
+template <int WPB, int LDSW>
+static void launch_geom(const DemodArgs& a, hipStream_t s) {
+    const int blocks = (a.n_streams + WPB - 1) / WPB;
+    hipLaunchKernelGGL((afsk::demod_kernel_t<0, true, WPB, LDSW>), dim3(blocks), dim3(64 * WPB), 0, s, a);
+}
+
 struct Variant { const char* name; launch_fn fn; bool exact; };
 
 int main(int argc, char** argv) {
@@ -84,6 +90,8 @@ int main(int argc, char** argv) {
         {"v1 two-pass", launch_flags<0, false>, true},
         {"v2 fast (nt)", launch_flags<0, true>, true},
         {"v2 fast default-policy", launch_flags<4, true>, true},
+        {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
+        {"wpb2 lds16K (10/CU)", launch_geom<2, 16384>, true},
         {"v2 skip_sync", launch_flags<1, true>, true},
         {"v2 skip_valu", launch_flags<2, true>, false},
         {"v2 skip_sync+valu", launch_flags<3, true>, false},
