@@ -415,3 +415,67 @@ def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     assert_same(got, want, "alignment shifts")
     assert len(set(int(c) & 7 for c in got.clock_idx)) == 8      # all 8 shifts were exercised
     assert (got.nbytes > 100).any() and (got.nbits % 14 != 0).any()
+
+
+def test_full_size_config3_mixed_baud_roundtrip(torch_cuda):
+    """BASELINE config #3 at full size (65536 x 1 s, baud = {300,1200,2400} by stream index,
+    6.3 GB): size-independent round trip (decoded == modulated payload for every stream) and
+    the oracle on a 192-stream sample."""
+    torch = torch_cuda
+    n = 65536
+    b = synth_batch(torch, n, (300, 1200, 2400), seed=3003)
+    stride = batch.out_stride_for(48000, 20)
+    res = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    assert (got.status == 0).all() and np.array_equal(got.nbytes, b["plen"])
+    assert (got.clock_idx == 0).all()
+    col = np.arange(b["payload"].shape[1])[None, :]
+    mask = col < b["plen"][:, None]
+    assert np.array_equal(np.where(mask, got.bytes[:, : b["payload"].shape[1]], 0),
+                          np.where(mask, b["payload"], 0))
+    sel = np.arange(0, n, n // 192)[:192]
+    h = b["samples"].view(n, -1)[torch.from_numpy(sel).to(b["samples"].device)].cpu().numpy().reshape(-1)
+    want = O.demod_batch(h, np.arange(len(sel), dtype=np.int64) * 48000,
+                         np.full(len(sel), 48000, np.int32), b["h_bf"][sel], 14000,
+                         out_stride=stride, n_threads=8)
+    sub = batch.HostDemodResult(got.bytes[sel], got.nbytes[sel], got.nbits[sel],
+                                got.clock_idx[sel], got.term_frame[sel], got.status[sel])
+    assert_same(sub, want, "config3 sample")
+    del b, res
+    torch.cuda.empty_cache()
+
+
+def test_config4_ber_curve_gpu_equals_cpu(torch_cuda):
+    """BASELINE config #4 shape: 1200 baud, SNR 30 -> 5 dB (plus 3 and 0 dB).  The GPU result
+    equals the oracle stream by stream, so the BER curves coincide exactly; BER is 0 at high
+    SNR and grows as the SNR falls (payload bit errors + 8 per missing/extra byte)."""
+    torch = torch_cuda
+    snrs = [30, 25, 20, 15, 10, 7, 5, 3, 0]
+    per = 96
+    snr = np.repeat(snrs, per)
+    b = synth_batch(torch, len(snr), (1200,), seed=4004, snr_db=snr)
+    stride = batch.out_stride_for(b["total"], 40)
+    got = batch.demod_batch(b["samples"], b["off"], b["ln"], 40, 14000, out_stride=stride).cpu()
+    want = O.demod_batch(b["samples"].cpu().numpy(), b["h_off"], b["h_ln"], b["h_bf"], 14000,
+                         out_stride=stride, n_threads=8)
+    assert_same(got, want, "ber sweep")
+
+    def ber(res_bytes, res_nbytes):
+        out = []
+        for k in range(len(snrs)):
+            errs = bits = 0
+            for s in range(k * per, (k + 1) * per):
+                nb = int(res_nbytes[s])
+                m = min(nb, 34)
+                x = np.unpackbits(res_bytes[s, :m] ^ b["payload"][s, :m]).sum()
+                errs += int(x) + 8 * abs(nb - 34)
+                bits += 34 * 8
+            out.append(errs / bits)
+        return out
+
+    g = ber(got.bytes, got.nbytes)
+    c = ber(want["bytes"], want["nbytes"])
+    assert g == c
+    assert g[0] == 0.0 and g[2] == 0.0 and g[4] == 0.0          # 30, 20, 10 dB error free
+    assert g[-1] > g[4]                                         # 0 dB is worse than 10 dB
