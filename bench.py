@@ -265,6 +265,15 @@ def main() -> None:
                     and want["bytes"][s, : min(nb, stride)].tobytes() == got_payloads[s][: min(nb, stride)])
             match += bool(same)
         del want1
+        # "reference-shaped" figure: the pure-Python restatement (oracle/pyref.py) on one core;
+        # in the dev container it runs at 1.01-1.07x the speed of the real afskmodem.py.
+        from oracle import pyref
+        npy = 3
+        t3 = time.perf_counter()
+        for s_i in range(npy):
+            data, _, _, _ = pyref.demod(h[s_i * STREAM_LEN: (s_i + 1) * STREAM_LEN].tolist(), int(bf_h[s_i]))
+            assert data == got_payloads[s_i], "pure-Python restatement disagrees with the GPU"
+        dtp = (time.perf_counter() - t3) / npy
         out["cpu_baseline"] = {
             "value": round(ns * STREAM_LEN / dtc / 1e6, 1), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
@@ -272,6 +281,10 @@ def main() -> None:
                       f"{cores} threads, {reps} reps; single thread on {ns // 8} streams: "
                       f"{round((ns // 8) * STREAM_LEN / dt1 / 1e6, 1)} Msamples/s",
             "single_thread_value": round((ns // 8) * STREAM_LEN / dt1 / 1e6, 1),
+            "python_reference_shaped_value": round(STREAM_LEN / dtp / 1e6, 3),
+            "python_reference_shaped_note": "oracle/pyref.py (pure-Python restatement, CPython, 1 core, "
+                                            f"{npy} streams); calibrated at 1.01-1.07x the real reference's "
+                                            "speed in the dev container (DESIGN.md 4.3)",
         }
         out["match_rate"] = match / ns
         out["match_sample_streams"] = ns

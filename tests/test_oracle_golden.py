@@ -123,3 +123,19 @@ def test_listen_gate_cases(golden):
         for (st, ln), b in zip(bursts, c["bursts"]):
             if ln == b["ref_len"]:      # closed burst: identical frames went into the reference
                 assert O.load_frames(cap[st: st + ln], 1200, c["amp_end"]).hex() == b["bytes_hex"], c["name"]
+
+
+def test_pure_python_restatement_matches_reference_vectors(golden):
+    """oracle/pyref.py (the interpreter-speed twin timed by bench.py) on a spread of the
+    reference-generated decode cases."""
+    from oracle import pyref
+    picked = [c for c in golden["decode_cases"]
+              if c["tag"] in ("clean/hello/1200", "clean/A/300", "clean/fffefd/2400", "exact4096",
+                              "too_short4000", "no_tail", "no_tail_plus1", "lead33", "amp_end_0",
+                              "noise/1200/snr5/seed0", "noise/1200/snr0/seed2", "noise/2400/snr3")]
+    assert len(picked) == 12
+    for c in picked:
+        x = build_input(c).tolist()
+        data, nbits, ci, term = pyref.demod(x, 48000 // c["baud"], c["amp_end"])
+        assert (ci, term, nbits, data.hex()) == (c["clock_idx"], c["term_frame"], c["nbits"],
+                                                 c["bytes_hex"]), c["tag"]
