@@ -479,3 +479,30 @@ def test_config4_ber_curve_gpu_equals_cpu(torch_cuda):
     assert g == c
     assert g[0] == 0.0 and g[2] == 0.0 and g[4] == 0.0          # 30, 20, 10 dB error free
     assert g[-1] > g[4]                                         # 0 dB is worse than 10 dB
+
+
+def test_random_garbage_streams(torch_cuda):
+    """Uniform full-range int16 garbage, constant extremes, and alternating full-scale values:
+    no training sequence, many false terminators, -32768 everywhere -- the integer paths
+    (abs(-32768) = 32768, limiter dead zone edges, SAD sums at their maxima) must still agree."""
+    torch = torch_cuda
+    rng = np.random.default_rng(2718)
+    pieces, bfs = [], []
+    for bf in (20, 40, 160, 80, 480, 8):
+        for L in (4096, 6000, 20000):
+            pieces.append(rng.integers(-32768, 32768, L).astype(np.int16)); bfs.append(bf)
+        pieces.append(np.full(9000, -32768, np.int16)); bfs.append(bf)
+        pieces.append(np.full(9000, 32767, np.int16)); bfs.append(bf)
+        pieces.append(np.tile(np.array([-32768, 32767], np.int16), 5000)); bfs.append(bf)
+        pieces.append(np.tile(np.array([512, -512, 513, -513, 0], np.int16), 2000)); bfs.append(bf)
+        sq = np.repeat(np.tile(np.array([32767, -32768], np.int16), 40000 // bf), bf // 2)
+        pieces.append(sq[:30000]); bfs.append(bf)            # a pure space tone: no terminator
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    bf = np.array(bfs, np.int32)
+    flat = np.concatenate(pieces)
+    for amp_end in (14000, 0):
+        got = device_demod(torch, flat, off, ln, bf, amp_end=amp_end, stride=512)
+        want = O.demod_batch(flat, off, ln, bf, amp_end, out_stride=512, n_threads=8)
+        assert_same(got, want, f"garbage amp_end={amp_end}")
+    assert (got.nbytes > 0).any()
