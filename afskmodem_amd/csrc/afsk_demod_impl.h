@@ -494,28 +494,32 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     st.npend = 0;
     int32_t n_sym = 0;
     int ci = 0;
-    if (FAST && (bf == 40 || bf == 20 || bf == 160)) {
-        if constexpr (FAST) {
-            switch (bf) {
-                case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
-                                                       (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
-                case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
-                                                       (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
-                default:  demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
-                                                        (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr); break;
-            }
+    bool done = false;
+    if constexpr (FAST) {   // single-pass ring kernel for the common bauds (afsk_demod_fast.h)
+        unsigned long long* stamps = (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr;
+        done = true;
+        switch (bf) {
+            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
+            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
+            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
+            default:  done = false; break;
         }
-    } else {
+    }
+    if (!done) {            // two-pass path: every other valid bit_frames (and all of them in the v1 build)
         if constexpr (!(FLAGS & kFlagSkipSync))
             ci = recover_clock_index(xs, len, bf, reinterpret_cast<int32_t*>(lds), lane);
         // phase B reuses the prefix-sum region: all LDS reads of phase A have returned
         // (their values were consumed), so the DMA writes below cannot overtake them.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        switch (bf) {
-            case 40:  demod_symbols<40, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-            case 20:  demod_symbols<20, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-            case 160: demod_symbols<160, 4, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-            default:  demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+        if constexpr (FAST) {
+            demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym);
+        } else {
+            switch (bf) {
+                case 40:  demod_symbols<40, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+                case 20:  demod_symbols<20, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+                case 160: demod_symbols<160, 4, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+                default:  demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+            }
         }
     }
     if (lane == 0) {
