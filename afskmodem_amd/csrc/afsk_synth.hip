@@ -60,13 +60,14 @@ __device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym,
 }
 
 // One block = 8192 consecutive output samples of one stream; one thread = 4 x (8 samples =
-// one 16-byte store).  The per-stream scalars and the block's payload window (staged in LDS)
-// are fetched once per block, so the global-load latency is paid once per 16 KiB written.  All
-// positions fit in 32 bits (stream_len < 2^30).  Per store one integer division locates the
-// first frame's symbol; a store touches at most 3 symbols (bf >= 4); the per-sample part is
-// branch-free.
+// one 16-byte store).  Per block, once: the per-stream scalars, the payload window (LDS) and a
+// bitmap of the tone kind of every symbol the block touches (one ballot per 64 symbols).  Per
+// store: three bitmap bits (a store touches at most 3 symbols, bf >= 4) and branch-free
+// phase arithmetic; positions fit in 32 bits (stream_len < 2^30), no division in the loop.
 __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     __shared__ uint8_t win[kModThreads];
+    // tone kind (1 = mark) of every symbol the block touches: at most 8192/4 + 2 symbols
+    __shared__ unsigned long long kinds[kModChunk / 4 / 64 + 2];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const uint32_t len = (uint32_t)a.stream_len[s];
@@ -95,6 +96,19 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
         win[threadIdx.x] = idx < plen ? payload[idx] : (uint8_t)0;
     }
     __syncthreads();
+    // Kind bitmap: bit r = symbol Sb + r.  Each wave ballots 64 consecutive symbols per pass.
+    {
+        const uint32_t last = (base + kModChunk - 1u) / bf + 2u;          // exclusive upper bound + slack
+        const uint32_t nsym_blk = last - Sb + 1u;
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        for (uint32_t r0 = wave * 64u; r0 < nsym_blk; r0 += kModThreads) {
+            const uint32_t S = Sb + r0 + lane;
+            const bool mk = S < n_sym && symbol_is_mark(S, n_train_sym, first_byte, win);
+            const unsigned long long m = __ballot(mk);
+            if (lane == 0) kinds[r0 >> 6] = m;
+        }
+    }
+    __syncthreads();
 
     // Symbol / phase of this thread's first store, then advanced by 2048 samples per iteration
     // without further divisions: x < bf + 2048 (bf < 2048), so a float estimate + fix-up is exact.
@@ -117,9 +131,11 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     for (int it = 0; it < kModIters; it++) {
         const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
         if (p0 >= len) break;
-        const bool k0 = symbol_is_mark(S0, n_train_sym, first_byte, win);
-        const bool k1 = symbol_is_mark(S0 + 1u, n_train_sym, first_byte, win);
-        const bool k2 = symbol_is_mark(S0 + 2u, n_train_sym, first_byte, win);
+        const uint32_t rel = S0 - Sb;                            // three consecutive bits of the bitmap
+        const unsigned long long w0 = kinds[rel >> 6], w1 = kinds[(rel >> 6) + 1u];
+        const uint32_t sh = rel & 63u;
+        const uint32_t kb = (uint32_t)(w0 >> sh) | (sh > 61u ? (uint32_t)(w1 << (64u - sh)) : 0u);
+        const bool k0 = kb & 1u, k1 = kb & 2u, k2 = kb & 4u;
         // tone of the frame at offset dj from p0 (branch-free)
         auto frame = [&](uint32_t dj) -> int16_t {
             const uint32_t phj = ph0 + dj;                      // < bf + 7 < 3*bf
