@@ -7,8 +7,9 @@
 //
 //   ring      16 x 1 KiB chunks; chunk c (samples 512c .. 512c+511) lives in slot
 //             c & 15; one `buffer_load_dwordx4 ... lds` per chunk, bounds-checked by
-//             a descriptor over the whole stream (tail reads return 0).  Chunks 0..11
-//             are requested at once; slots 12..15 hold phase A's prefix window first.
+//             a descriptor over the whole stream (tail reads return 0).  All 16 chunks
+//             are requested at once (300 baud: 12, its larger prefix window borrows
+//             slots 12..15 during phase A).
 //   phase A   ref:322-339 on the first 8 chunks as they land (progressive vmcnt):
 //             a producer turns 256 raw samples per step into exclusive prefix sums
 //             (DPP wave scan) kept in a 512/1024-entry circular window; a consumer
@@ -103,11 +104,21 @@ struct SyncGeom {
     // BF <= 64: the first N entries of every even producer step are stored a second time past
     // the end of the window, so a consumer's reads never wrap and need no address masking.
     static constexpr int MIRROR = BF <= 64 ? ((N + 3) / 4) * 4 : 0;
-    static_assert((PW + MIRROR) * 4 <= 4096, "window must fit ring slots 12..15");
+    static constexpr int WIN_BYTES = (PW + MIRROR) * 4;
+    // Where the window lives and how much of the stream is requested before phase A:
+    //   BF <= 64  2.4 KiB window in its own LDS behind the ring; all 16 chunks requested up
+    //             front (phase A takes about as long as 16 KiB take to arrive);
+    //   BF  > 64  4 KiB window inside ring slots 12..15; chunks 0..11 requested up front, the
+    //             rest right after phase A.
+    static constexpr bool WIN_IN_RING = BF > 64;
+    static constexpr int SYNC_CHUNKS = WIN_IN_RING ? 12 : kRingChunks;
+    static constexpr int WIN_OFFSET = WIN_IN_RING ? 12 * 1024 : kRingBytes;
+    static_assert(!WIN_IN_RING || WIN_BYTES <= 4096, "window must fit ring slots 12..15");
 };
-constexpr int kSyncChunks = 12;                                // chunks requested before phase A
-constexpr int kPWinOffset = kSyncChunks * 1024;                // window = ring bytes [12 KiB, 16 KiB)
-constexpr int kFastWaveLds = kRingBytes;
+constexpr int kWinExtraBytes = 2560;                           // own-LDS window of the BF <= 64 paths
+static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
+              "window LDS too small");
+constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
@@ -131,7 +142,7 @@ __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* p
     auto load_raw = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         if constexpr (u < G::PSTEPS) {
-            if constexpr ((u & 1) == 0) wait_vmcnt<kSyncChunks - 1 - u / 2>();   // chunk u/2 has landed
+            if constexpr ((u & 1) == 0) wait_vmcnt<G::SYNC_CHUNKS - 1 - u / 2>();   // chunk u/2 has landed
             if constexpr (u == 0) { if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime(); }
             raw_next = *reinterpret_cast<const u32x2*>(fr.ring + 512 * u + 8 * lane);
         }
@@ -435,15 +446,16 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
     fr.lane = lane;
+    using G = SyncGeom<BF>;
 #pragma unroll
-    for (int c = 0; c < kSyncChunks; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
-    fr.next = kSyncChunks;                                  // slots 12..15 hold the prefix window
+    for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
+    fr.next = G::SYNC_CHUNKS;
 
     int ci = 0;
     if constexpr (FLAGS & 1) {
-        wait_vmcnt<kSyncChunks - 8>();
+        wait_vmcnt<G::SYNC_CHUNKS - 8>();
     } else {
-        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + kPWinOffset), nullptr,
+        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), nullptr,
                                           (FLAGS & 64) ? stamps : nullptr);
     }
     ci_out = ci;

@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
         {"v2 fast (nt)", launch_flags<0, true>, true},
         {"v2 fast default-policy", launch_flags<4, true>, true},
         {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
-        {"wpb2 lds16K (10/CU)", launch_geom<2, 16384>, true},
+        {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},
         {"v2 skip_sync", launch_flags<1, true>, true},
         {"v2 skip_valu", launch_flags<2, true>, false},
         {"v2 skip_sync+valu", launch_flags<3, true>, false},

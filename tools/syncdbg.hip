@@ -13,9 +13,10 @@ __global__ __launch_bounds__(64) void k_sync(const int16_t* xs, int32_t len, uin
     afsk::FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds; fr.lane = threadIdx.x;
-    for (int c = 0; c < afsk::kSyncChunks; c++) fr.issue(c);
-    fr.next = afsk::kSyncChunks;
-    int ci = afsk::recover_clock_index_fast<BF, true>(fr, reinterpret_cast<int32_t*>(lds + afsk::kPWinOffset), dbg);
+    using G = afsk::SyncGeom<BF>;
+    for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.issue(c);
+    fr.next = G::SYNC_CHUNKS;
+    int ci = afsk::recover_clock_index_fast<BF, true>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), dbg);
     afsk::wait_vmcnt<0>();
     if (threadIdx.x == 0) *ci_out = ci;
 }
