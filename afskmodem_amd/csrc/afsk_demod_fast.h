@@ -285,11 +285,113 @@ __device__ __forceinline__ uint32_t abs_sum(const uint32_t (&x)[20]) {   // ref:
     return a;
 }
 
+// ---- phase C for the single-pass kernel: deferred Hamming decode -------------------------
+// Every pass only (a) scans for the training terminator, (b) once in the data phase checks the
+// squelch stop, and (c) parks its symbol decisions in a small circular bit buffer in LDS (bit
+// g % 64 of word (g / 64) % kBitWords = decision of symbol g).  The ECC decode + byte pack
+// (ref:145-163, 393-399) runs vectorised, one lane per output byte, whenever 64 bytes are
+// ready and once at the end -- instead of ~100 dependent scalar instructions per pass.
+constexpr int kBitWords = 64;                                   // 4096 symbols of history
+
+struct RxDeferred {
+    RxState st;               // phase / hist / term_sym as in the per-pass state machine
+    int32_t end_sym;          // first symbol index past the data (valid once st.phase == 2)
+    int32_t bytes_done;       // decoded bytes already stored
+    int32_t filled;           // symbols parked so far (a multiple of the pass size)
+    uint64_t cur;             // bits of the 64-symbol word being filled
+};
+
+__device__ __forceinline__ void rxd_init(RxDeferred& d) {
+    d.st.phase = 0; d.st.hist = 0; d.st.nbits = 0; d.st.nbytes = 0; d.st.term_sym = -1;
+    d.st.pend = 0; d.st.npend = 0;
+    d.end_sym = 0; d.bytes_done = 0; d.filled = 0; d.cur = 0;
+}
+
+// squelch stop inside a pass whose data symbols start at `start` (ref:372-376)
+__device__ __forceinline__ void rxd_stop(RxDeferred& d, uint64_t amp_ok, int start, int nv, int k0) {
+    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    const uint64_t stop = valid & ~((1ull << start) - 1ull) & ~amp_ok;     // start < 64
+    if (stop) {
+        d.end_sym = k0 + __builtin_ctzll(stop);
+        d.st.phase = 2;
+    }
+}
+
+// park the PS decisions of the pass that starts at symbol k0 (k0 % PS == 0, 64 % PS == 0)
+template <int PS>
+__device__ __forceinline__ void rxd_store(RxDeferred& d, uint64_t bits, int nv, int k0, int lane,
+                                          unsigned long long* words) {
+    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    d.filled = k0 + PS;
+    if constexpr (PS == 64) {
+        if (lane == 0) words[(k0 >> 6) & (kBitWords - 1)] = bits & valid;
+    } else {
+        d.cur |= (bits & valid) << (k0 & 63);
+        if (((k0 & 63) + PS) == 64) {
+            if (lane == 0) words[(k0 >> 6) & (kBitWords - 1)] = d.cur;
+            d.cur = 0;
+        }
+    }
+}
+
+// decode and store every byte whose 14 coded bits lie below symbol index `avail`
+template <int PS>
+__device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
+                                          unsigned long long* words, uint8_t* out_row, int out_stride) {
+    if (d.st.term_sym < 0 || avail <= d.st.term_sym) return;
+    const int jnew = (avail - d.st.term_sym) / 14;
+    if (jnew <= d.bytes_done) return;
+    if constexpr (PS != 64) {         // a partly filled word is not in LDS yet
+        if ((d.filled & 63) != 0 && lane == 0) words[(d.filled >> 6) & (kBitWords - 1)] = d.cur;
+    }
+    wave_lds_sync();                  // lane 0 stored the words, every lane reads them
+    for (int j0 = d.bytes_done; j0 < jnew; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < jnew) {
+            const int g = d.st.term_sym + 14 * j;
+            const uint64_t lo = words[(g >> 6) & (kBitWords - 1)];
+            const uint64_t hi = words[((g >> 6) + 1) & (kBitWords - 1)];
+            const int sh = g & 63;
+            uint32_t c = (uint32_t)(lo >> sh);
+            if (sh > 50) c |= (uint32_t)(hi << (64 - sh));
+            c &= 0x3FFFu;
+            const uint32_t byte = (hamming_nibble(c & 127u) << 4) | hamming_nibble(c >> 7);   // ref:393-399
+            if (j < out_stride) out_row[j] = (uint8_t)byte;
+        }
+    }
+    wave_lds_sync();                  // later passes overwrite old words
+    d.bytes_done = jnew;
+}
+
+// one pass of PS symbols: terminator scan, lazy squelch amplitude, park the bits, maybe flush
+template <int PS, class AmpFn>
+__device__ __forceinline__ void rxd_pass(RxDeferred& d, uint64_t bmask, int nv, int k0, int lane,
+                                         unsigned long long* words, uint8_t* out_row, int out_stride,
+                                         AmpFn&& amp_ok_mask) {
+    const int start = rx_training(d.st, bmask, nv, k0);
+    if (start >= 0 && start < nv) rxd_stop(d, amp_ok_mask(), start, nv, k0);
+    rxd_store<PS>(d, bmask, nv, k0, lane, words);
+    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
+        rxd_flush<PS>(d, k0 + nv, lane, words, out_row, out_stride);
+}
+
+// end of stream: K symbols were examined unless the squelch stopped earlier
+template <int PS>
+__device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, unsigned long long* words,
+                                           uint8_t* out_row, int out_stride) {
+    if (d.st.term_sym < 0) { d.st.nbits = 0; d.st.nbytes = 0; return; }
+    const int end = d.st.phase == 2 ? d.end_sym : K;
+    d.st.nbits = end > d.st.term_sym ? end - d.st.term_sym : 0;
+    d.st.nbytes = d.st.nbits / 14;
+    rxd_flush<PS>(d, end, lane, words, out_row, out_stride);
+}
+
 // One 5 KiB round: symbol decisions, then (only once the training terminator has been
 // seen) squelch amplitudes, Hamming decode and byte pack.
 template <int BF, int FLAGS>
 __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int lane, uint32_t amp_thr,
-                                                   int32_t K, int k0, RxState& st, uint8_t* out_row,
+                                                   int32_t K, int k0, RxDeferred& rd,
+                                                   unsigned long long* words, uint8_t* out_row,
                                                    int out_stride) {
     constexpr int Q = BF / 4, H = BF / 2;
     constexpr uint32_t FULL = 65535u;
@@ -309,13 +411,11 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         }
         const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);     // ref:348-351
         const int nv = (K - k0) < 64 ? (K - k0) : 64;
-        const uint64_t bmask = __ballot(bit);
-        const int start = rx_training(st, bmask, nv, k0);
-        if (start >= 0 && start < nv) {
+        rxd_pass<64>(rd, __ballot(bit), nv, k0, lane, words, out_row, out_stride, [&]() {
             uint32_t amp = 0x7fffffffu;
             if constexpr (!(FLAGS & 2)) amp = abs_sum<0, 20>(x);
-            rx_data(st, bmask, __ballot(amp >= amp_thr), start, nv, lane, out_row, out_stride);
-        }
+            return __ballot(amp >= amp_thr);
+        });
     } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 and 10-19
         uint32_t mk[2] = {0, 0}, sp[2] = {0, 0};
 #pragma unroll
@@ -334,17 +434,15 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int kk = k0 + 64 * half;
-            if (kk >= K || st.phase == 2) break;
+            if (kk >= K || rd.st.phase == 2) break;
             const int nv = (K - kk) < 64 ? (K - kk) : 64;
             const int vb = __shfl(pkb, 32 * half + (lane >> 1), 64) >> (lane & 1);
-            const uint64_t bmask = __ballot(vb & 1);
-            const int start = rx_training(st, bmask, nv, kk);
-            if (start >= 0 && start < nv) {
+            rxd_pass<64>(rd, __ballot(vb & 1), nv, kk, lane, words, out_row, out_stride, [&]() {
                 if (pka < 0)
                     pka = (int)(abs_sum<0, 10>(x) >= amp_thr) | ((int)(abs_sum<10, 20>(x) >= amp_thr) << 1);
                 const int va = __shfl(pka, 32 * half + (lane >> 1), 64) >> (lane & 1);
-                rx_data(st, bmask, __ballot(va & 1), start, nv, lane, out_row, out_stride);
-            }
+                return __ballot(va & 1);
+            });
         }
     } else {                                  // BF == 160: four lanes per symbol, one quarter each
         static_assert(BF == 160, "fast path supports bit_frames 20, 40, 160");
@@ -362,14 +460,12 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         const int srcl = (lane * 4) & 63;                          // lane j < 16 <- symbol j
         const int nv = (K - k0) < 16 ? (K - k0) : 16;
         const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < 16);
-        const int start = rx_training(st, bmask, nv, k0);
-        if (start >= 0 && start < nv) {
+        rxd_pass<16>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
             uint32_t amp = abs_sum<0, 20>(x);
 #pragma unroll
             for (int s = 1; s < 4; s <<= 1) amp += (uint32_t)__shfl_xor((int)amp, s, 64);
-            const uint64_t amask = __ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < 16);
-            rx_data(st, bmask, amask, start, nv, lane, out_row, out_stride);
-        }
+            return (uint64_t)__ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < 16);
+        });
     }
 }
 
@@ -378,7 +474,8 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
 // five aligned ds_read_b128 feed the arithmetic directly.  Otherwise six reads + v_alignbyte.
 template <int BF, int FLAGS, bool ALIGNED>
 __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
-                                            uint32_t amp_thr, RxState& st, uint8_t* out_row,
+                                            uint32_t amp_thr, RxDeferred& rd,
+                                            unsigned long long* words, uint8_t* out_row,
                                             int out_stride) {
     constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
     const int lane = fr.lane;
@@ -430,8 +527,8 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
 #pragma unroll
         for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
         fr.next += 5;
-        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, st, out_row, out_stride);
-        if (st.phase == 2) break;
+        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, rd, words, out_row, out_stride);
+        if (rd.st.phase == 2) break;
     }
 }
 
@@ -476,8 +573,15 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         const int lim = (byte0 >> 10) + kRingChunks;
         while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
     }
-    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, st, out_row, out_stride);
-    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, st, out_row, out_stride);
+    // phase C state; its bit buffer reuses the LDS behind the ring (phase A's window is done)
+    constexpr int PS = BF == 160 ? 16 : 64;
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
+    RxDeferred rd;
+    rxd_init(rd);
+    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride);
+    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride);
+    rxd_finish<PS>(rd, K, lane, words, out_row, out_stride);
+    st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
