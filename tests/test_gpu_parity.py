@@ -506,3 +506,25 @@ def test_random_garbage_streams(torch_cuda):
         want = O.demod_batch(flat, off, ln, bf, amp_end, out_stride=512, n_threads=8)
         assert_same(got, want, f"garbage amp_end={amp_end}")
     assert (got.nbytes > 0).any()
+
+
+def test_max_size_config5_on_one_gpu(torch_cuda):
+    """BASELINE config #5's whole stream count (524288 x 1 s @1200 baud = 50 GB, normally
+    sharded over 8 GPUs) on ONE MI355X: every stream decodes to its payload, and a
+    checksum of all decoded bytes equals the checksum of the modulated payloads."""
+    torch = torch_cuda
+    n = 524288
+    free, _ = torch.cuda.mem_get_info()
+    if free < 62 * 2 ** 30:
+        pytest.skip("needs ~55 GB of free HBM")
+    b = synth_batch(torch, n, (1200,), seed=5005)
+    stride = batch.out_stride_for(48000, 40)
+    res = batch.demod_batch(b["samples"], b["off"], b["ln"], 40, 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    assert (got.status == 0).all() and (got.nbytes == 34).all() and (got.nbits == 476).all()
+    assert (got.clock_idx == 0).all() and (got.term_frame == 24160).all()
+    assert np.array_equal(got.bytes[:, :34], b["payload"][:, :34])
+    assert int(got.bytes[:, :34].astype(np.uint64).sum()) == int(b["payload"][:, :34].astype(np.uint64).sum())
+    del b, res
+    torch.cuda.empty_cache()
