@@ -2,6 +2,7 @@
 // (cdna_hip_programming.md rule 24).  Diagnostic tool, not part of the product.
 //   ./kbench [n_streams=4096] [baud=1200] [rounds=15] [reps=5]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -27,6 +28,25 @@ template <int WPB, int LDSW>
 static void launch_geom(const DemodArgs& a, hipStream_t s) {
     const int blocks = (a.n_streams + WPB - 1) / WPB;
     hipLaunchKernelGGL((afsk::demod_kernel_t<0, true, WPB, LDSW>), dim3(blocks), dim3(64 * WPB), 0, s, a);
+}
+
+// same kernel over 4 rotating copies of the input (1.6 GB working set at 4096 streams): defeats
+// any reuse of the 256 MiB Infinity Cache between back-to-back launches
+static const int16_t* g_copies[4] = {nullptr, nullptr, nullptr, nullptr};
+static int g_rot = 0;
+static void launch_rotating(const DemodArgs& a, hipStream_t s) {
+    DemodArgs b = a;
+    b.samples = g_copies[(g_rot++) & 3];
+    launch_flags<0, true>(b, s);
+}
+
+// the product library's entry point (same kernel, compiled in its own translation unit)
+typedef int (*lib_demod_fn)(const int16_t*, const int64_t*, const int32_t*, const int32_t*, int32_t, int32_t,
+                            uint8_t*, int32_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, void*);
+static lib_demod_fn g_lib_demod = nullptr;
+static void launch_lib(const DemodArgs& a, hipStream_t s) {
+    g_lib_demod(a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
+                a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
 }
 
 struct Variant { const char* name; launch_fn fn; bool exact; };
@@ -116,6 +136,24 @@ int main(int argc, char** argv) {
         int late = 0; for (int s = 0; s < n; s++) late += ((st[4 * s] - t0) * 0.01 > 10.0);
         printf("  waves starting later than 10 us after launch: %d of %d\n", late, n);
         CK(hipFree(d_st));
+    }
+    if (n <= 8192) {
+        g_copies[0] = d_x;
+        for (int c = 1; c < 4; c++) {
+            int16_t* p; CK(hipMalloc(&p, (size_t)n * L * 2));
+            CK(hipMemcpy(p, d_x, (size_t)n * L * 2, hipMemcpyDeviceToDevice));
+            g_copies[c] = p;
+        }
+        vs.insert(vs.begin() + 2, Variant{"v2 fast, 4 rotating inputs", launch_rotating, true});
+    }
+    if (void* h = dlopen("../afskmodem_amd/csrc/libafsk_amd.so", RTLD_NOW)) {
+        g_lib_demod = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
+        if (g_lib_demod) vs.insert(vs.begin() + 2, Variant{"libafsk_amd.so entry", launch_lib, true});
+    }
+    if (const char* only = getenv("KBENCH_ONLY")) {          // run a single variant (cache-state studies)
+        std::vector<Variant> keep;
+        for (auto& v : vs) if (strstr(v.name, only)) keep.push_back(v);
+        if (!keep.empty()) vs = keep;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> times(vs.size());
