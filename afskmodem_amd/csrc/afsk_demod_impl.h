@@ -1,25 +1,20 @@
-// afsk_demod_impl.h -- device code of the batched demodulator (included by afsk_demod.hip
-// and by the kernel micro-benchmark tools/kbench.hip).
-#pragma once
-// afsk_demod.hip -- batched AFSK demodulation for MI355X (gfx950 / CDNA4).
+// afsk_demod_impl.h -- device code of the batched AFSK demodulator for MI355X (gfx950 /
+// CDNA4).  Included by afsk_demod.hip (the product instantiation) and by the kernel
+// micro-benchmark tools/kbench.hip.
 //
-// One wavefront (64 lanes) owns one stream and runs the whole receiver hot path
-// of lavajuno/afskmodem for it (reference afskmodem.py, "ref:" below):
+// One wavefront (64 lanes) owns one stream and runs the whole receiver hot path of
+// lavajuno/afskmodem for it (reference afskmodem.py, "ref:" below): clock recovery
+// ref:322-339, per-symbol mark/space decisions ref:342-351 with the limiter ref:287-296,
+// training-terminator scan ref:361-366/386-390, squelch stop ref:372-378 with the amplitude
+// of ref:94-98, Hamming(7,4) decode ref:145-163 and MSB-first byte pack ref:393-399.
 //
-//   phase A  clock recovery, ref:322-339   prefix sums of the first 4096 raw
-//            samples in LDS; each sync offset's SAD against the training cycle
-//            is 7 prefix lookups (|hi - x| = 32767 - x and |lo - x| = x + 32768
-//            need no abs for int16 x); first argmin of the truncated means via a
-//            packed (mean << 12 | offset) wave-min.
-//   phase B  symbol decisions, ref:342-351 + limiter ref:287-296 + squelch
-//            amplitude ref:94-98.  The stream is re-read from the clock index as
-//            an LDS-DMA ring (buffer_load_dwordx4 ... lds, 1 KiB per wave
-//            instruction, bounds-checked by the buffer descriptor), so symbol k
-//            sits at LDS byte k*2*bf and every lane reduces one symbol piece with
-//            packed-int16 VALU + v_sad_u16.
-//   phase C  training terminator scan ref:361-366/386-390, squelch stop
-//            ref:372-378, Hamming(7,4) decode ref:145-163 and MSB-first byte pack
-//            ref:393-399 on 64-bit ballot masks (wave-uniform scalar code).
+// Two implementations share this file's helpers:
+//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for bit_frames 20 / 40 / 160
+//     (2400 / 1200 / 300 baud); every sample is fetched from HBM exactly once.
+//   * the two-pass path below (recover_clock_index + demod_symbols*): a full 4096-entry prefix
+//     array for phase A, then a clock-index-aligned ring; used for every other valid
+//     bit_frames (demod_symbols_generic) and, with FAST = false, as the round-1 v1 kernel of
+//     the common bauds in kbench A/B runs.
 //
 // No MFMA: this is an HBM-bound streaming reduction (2 B read per sample).
 // No workgroup barrier: the 4 waves of a block are independent streams.
