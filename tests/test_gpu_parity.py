@@ -528,3 +528,30 @@ def test_max_size_config5_on_one_gpu(torch_cuda):
     assert int(got.bytes[:, :34].astype(np.uint64).sum()) == int(b["payload"][:, :34].astype(np.uint64).sum())
     del b, res
     torch.cuda.empty_cache()
+
+
+def test_launch_is_graph_capture_safe(torch_cuda):
+    """The C-ABI launch path does no allocation / synchronisation, so a sequence of demod
+    launches can be captured into a HIP graph and replayed (guideline: no hipMalloc / sync in
+    the launch function)."""
+    torch = torch_cuda
+    b = synth_batch(torch, 256, (300, 1200, 2400), seed=99)
+    stride = batch.out_stride_for(48000, 20)
+    ref_out = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride).cpu()
+    outs = [batch.alloc_result(256, stride, "cuda:0") for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for o in outs:
+                batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out=o, stream=side)
+    for o in outs:
+        o.flat.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for o in outs:
+        got = o.cpu()
+        for f in FIELDS:
+            assert np.array_equal(getattr(got, f), getattr(ref_out, f)), f
+        assert np.array_equal(got.bytes, ref_out.bytes)
