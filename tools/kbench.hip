@@ -135,6 +135,16 @@ int main(int argc, char** argv) {
         // generation split: streams in first half of block ids vs second half
         int late = 0; for (int s = 0; s < n; s++) late += ((st[4 * s] - t0) * 0.01 > 10.0);
         printf("  waves starting later than 10 us after launch: %d of %d\n", late, n);
+        // per-XCD view (blocks are dealt round-robin over the 8 XCDs: block b -> group b % 8)
+        printf("  wave lifetime by block %% 8 (median us):");
+        for (int x = 0; x < 8; x++) {
+            std::vector<double> v;
+            for (int s = 0; s < n; s++) if (((s / 4) % 8) == x) v.push_back((st[4 * s + 3] - st[4 * s]) * 0.01);
+            std::sort(v.begin(), v.end());
+            printf(" %.1f", v.empty() ? 0.0 : v[v.size() / 2]);
+        }
+        printf("\n  kernel span (first start -> last end): %.2f us; last gen-1 end %.2f, first gen-2 start %.2f\n",
+               pct(3, 1.0), pct(3, 0.4999), pct(0, 0.5001));
         CK(hipFree(d_st));
     }
     if (n <= 8192) {
