@@ -100,6 +100,18 @@ class DemodResult:
     clock_idx: "object"
     term_frame: "object"
     status: "object"
+    # soft outputs, present only for demod_batch(..., diagnostics=True)
+    corrected: "object" = None   # int32 [n] codewords with a non-zero Hamming syndrome
+    margins: "object" = None     # int32 [n, margin_stride] space_diff - mark_diff per symbol
+
+    def symbols_demodulated(self, bit_frames) -> "object":
+        """int64 [n]: how many leading entries of each ``margins`` row are defined (the symbols
+        the reference's __decodeBits demodulated: training + data up to the squelch/end)."""
+        torch = _torch()
+        bf = torch.as_tensor(bit_frames, device=self.nbits.device).to(torch.int64)
+        found = (self.term_frame.to(torch.int64) - self.clock_idx.to(torch.int64)) // bf \
+            + self.nbits.to(torch.int64)
+        return found
 
     def cpu(self) -> HostDemodResult:
         return HostDemodResult(*(t.cpu().numpy() for t in
@@ -160,7 +172,8 @@ def _stream_ptr(stream):
 
 def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshold: int = 14000,
                 out: DemodResult | None = None, out_stride: int | None = None, stream=None,
-                validate: bool = True) -> DemodResult:
+                validate: bool = True, diagnostics: bool = False,
+                margin_stride: int | None = None) -> DemodResult:
     """One kernel launch over n independent streams resident in HBM.
 
     samples        int16 CUDA tensor holding every stream
@@ -168,6 +181,10 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
     stream_len     int32 CUDA tensor [n]
     bit_frames     int, sequence or tensor [n]: 48000 / baud per stream
     out            preallocated DemodResult to reuse (no allocation in the call)
+    diagnostics    also return the soft outputs of afsk_demod_batch_ex: ``corrected`` [n] and
+                   ``margins`` [n, margin_stride] (margin_stride symbols per row; pass e.g.
+                   max_stream_len // min(bit_frames)); rows are defined up to
+                   ``DemodResult.symbols_demodulated``
     Asynchronous on ``stream`` (default: torch's current stream).
     """
     torch = _torch()
@@ -190,6 +207,21 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
             raise ValueError("pass out= or out_stride=")
         out = alloc_result(n, int(out_stride), dev)
     stride = int(out.bytes.shape[1])
+    if diagnostics:
+        if out.corrected is None:
+            out.corrected = torch.zeros(n, dtype=torch.int32, device=dev)
+        if out.margins is None:
+            if margin_stride is None:
+                raise ValueError("diagnostics=True needs margin_stride= (symbols per margins row)")
+            out.margins = torch.zeros((n, int(margin_stride)), dtype=torch.int32, device=dev)
+        _native.check(_native.lib().afsk_demod_batch_ex(
+            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
+            int(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+            out.status.data_ptr(), out.corrected.data_ptr(), out.margins.data_ptr(),
+            int(out.margins.shape[1]), _stream_ptr(stream)))
+        out._bf_keepalive = bf  # type: ignore[attr-defined]
+        return out
     _native.check(_native.lib().afsk_demod_batch(
         samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
         int(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),

@@ -74,7 +74,21 @@ int afsk_demod_batch(const int16_t* samples, const int64_t* stream_offset,
                      int32_t out_stride, int32_t* out_nbytes, int32_t* out_nbits,
                      int32_t* out_clock_idx, int32_t* out_term_frame, int32_t* out_status,
                      void* hip_stream) {
-    if (n_streams < 0 || out_stride < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    return afsk_demod_batch_ex(samples, stream_offset, stream_len, bit_frames, amp_end_threshold,
+                               n_streams, out_bytes, out_stride, out_nbytes, out_nbits,
+                               out_clock_idx, out_term_frame, out_status, nullptr, nullptr, 0,
+                               hip_stream);
+}
+
+int afsk_demod_batch_ex(const int16_t* samples, const int64_t* stream_offset,
+                        const int32_t* stream_len, const int32_t* bit_frames,
+                        int32_t amp_end_threshold, int32_t n_streams, uint8_t* out_bytes,
+                        int32_t out_stride, int32_t* out_nbytes, int32_t* out_nbits,
+                        int32_t* out_clock_idx, int32_t* out_term_frame, int32_t* out_status,
+                        int32_t* out_corrected, int32_t* out_margins, int32_t margin_stride,
+                        void* hip_stream) {
+    if (n_streams < 0 || out_stride < 0 || margin_stride < 0)
+        return fail(AFSK_E_INVALID_ARG, "negative size");
     if (n_streams == 0) return AFSK_OK;
     if (!samples || !stream_offset || !stream_len || !bit_frames || !out_nbytes || !out_nbits ||
         !out_clock_idx || !out_term_frame || !out_status || (!out_bytes && out_stride > 0))
@@ -86,6 +100,9 @@ int afsk_demod_batch(const int16_t* samples, const int64_t* stream_offset,
     a.out_bytes = out_bytes; a.out_stride = out_stride; a.out_nbytes = out_nbytes;
     a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
     a.out_status = out_status;
+    a.out_corrected = out_corrected;
+    a.out_margins = margin_stride > 0 ? out_margins : nullptr;
+    a.margin_stride = margin_stride;
     hipError_t e = afsk::launch_demod(a, (hipStream_t)hip_stream);
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel");
 }

@@ -303,7 +303,7 @@ struct RxDeferred {
 
 __device__ __forceinline__ void rxd_init(RxDeferred& d) {
     d.st.phase = 0; d.st.hist = 0; d.st.nbits = 0; d.st.nbytes = 0; d.st.term_sym = -1;
-    d.st.pend = 0; d.st.npend = 0;
+    d.st.pend = 0; d.st.npend = 0; d.st.corrected = 0;
     d.end_sym = 0; d.bytes_done = 0; d.filled = 0; d.cur = 0;
 }
 
@@ -347,6 +347,7 @@ __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
     wave_lds_sync();                  // lane 0 stored the words, every lane reads them
     for (int j0 = d.bytes_done; j0 < jnew; j0 += 64) {
         const int j = j0 + lane;
+        bool fix0 = false, fix1 = false;       // soft output: non-zero syndromes (ref:147)
         if (j < jnew) {
             const int g = d.st.term_sym + 14 * j;
             const uint64_t lo = words[(g >> 6) & (kBitWords - 1)];
@@ -357,7 +358,10 @@ __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
             c &= 0x3FFFu;
             const uint32_t byte = (hamming_nibble(c & 127u) << 4) | hamming_nibble(c >> 7);   // ref:393-399
             if (j < out_stride) out_row[j] = (uint8_t)byte;
+            fix0 = hamming_syndrome(c & 127u) != 0;
+            fix1 = hamming_syndrome(c >> 7) != 0;
         }
+        d.st.corrected += (int32_t)__popcll(__ballot(fix0)) + (int32_t)__popcll(__ballot(fix1));
     }
     wave_lds_sync();                  // later passes overwrite old words
     d.bytes_done = jnew;
@@ -384,6 +388,19 @@ __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, u
     d.st.nbits = end > d.st.term_sym ? end - d.st.term_sym : 0;
     d.st.nbytes = d.st.nbits / 14;
     rxd_flush<PS>(d, end, lane, words, out_row, out_stride);
+    if ((d.st.nbits / 7) & 1) {       // ECC.decode also corrects an odd last codeword (ref:157-162)
+        if constexpr (PS != 64) {
+            if ((d.filled & 63) != 0 && lane == 0) words[(d.filled >> 6) & (kBitWords - 1)] = d.cur;
+        }
+        wave_lds_sync();
+        const int g = d.st.term_sym + 14 * d.st.nbytes;
+        const uint64_t lo = words[(g >> 6) & (kBitWords - 1)];
+        const uint64_t hi = words[((g >> 6) + 1) & (kBitWords - 1)];
+        const int sh = g & 63;
+        uint32_t c = (uint32_t)(lo >> sh);
+        if (sh > 57) c |= (uint32_t)(hi << (64 - sh));
+        d.st.corrected += hamming_syndrome(c & 127u) != 0;
+    }
 }
 
 // One 5 KiB round: symbol decisions, then (only once the training terminator has been
@@ -392,8 +409,9 @@ template <int BF, int FLAGS>
 __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int lane, uint32_t amp_thr,
                                                    int32_t K, int k0, RxDeferred& rd,
                                                    unsigned long long* words, uint8_t* out_row,
-                                                   int out_stride) {
+                                                   int out_stride, int32_t* margins, int32_t mstride) {
     constexpr int Q = BF / 4, H = BF / 2;
+    const int32_t mlim = K < mstride ? K : mstride;      // soft output rows hold symbols [0, mlim)
     constexpr uint32_t FULL = 65535u;
     if constexpr (BF == 40) {                 // one symbol per lane, 5 dwords per quarter
         uint32_t mark, space;
@@ -409,7 +427,9 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             mark = 2u * FULL * Q + h0 + h2 - h1 - h3;
             space = 2u * FULL * Q + h0 + h1 - h2 - h3;
         }
-        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);     // ref:348-351
+        const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+        const bool bit = md < sd;                                            // ref:348-351
+        if (margins && k0 + lane < mlim) margins[k0 + lane] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < 64 ? (K - k0) : 64;
         rxd_pass<64>(rd, __ballot(bit), nv, k0, lane, words, out_row, out_stride, [&]() {
             uint32_t amp = 0x7fffffffu;
@@ -427,8 +447,14 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             mk[h2] = __builtin_amdgcn_sad_u16(lim, tm, mk[h2]);
             sp[h2] = __builtin_amdgcn_sad_u16(lim, ts, sp[h2]);
         }
-        const int pkb = (int)((mk[0] / (uint32_t)BF) < (sp[0] / (uint32_t)BF)) |
-                        ((int)((mk[1] / (uint32_t)BF) < (sp[1] / (uint32_t)BF)) << 1);
+        const uint32_t md0 = mk[0] / (uint32_t)BF, sd0 = sp[0] / (uint32_t)BF;
+        const uint32_t md1 = mk[1] / (uint32_t)BF, sd1 = sp[1] / (uint32_t)BF;
+        const int pkb = (int)(md0 < sd0) | ((int)(md1 < sd1) << 1);
+        if (margins) {
+            const int k = k0 + 2 * lane;
+            if (k < mlim) margins[k] = (int32_t)sd0 - (int32_t)md0;
+            if (k + 1 < mlim) margins[k + 1] = (int32_t)sd1 - (int32_t)md1;
+        }
         int pka = -1;                          // amplitudes computed lazily, once per round
         // symbol j of this round lives in lane j/2, half j%2: two passes of 64 symbols
 #pragma unroll
@@ -456,7 +482,10 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             mark += (uint32_t)__shfl_xor((int)mark, s, 64);
             space += (uint32_t)__shfl_xor((int)space, s, 64);
         }
-        const bool bit = (mark / (uint32_t)BF) < (space / (uint32_t)BF);
+        const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+        const bool bit = md < sd;
+        if (margins && quarter == 0 && k0 + (lane >> 2) < mlim)
+            margins[k0 + (lane >> 2)] = (int32_t)sd - (int32_t)md;
         const int srcl = (lane * 4) & 63;                          // lane j < 16 <- symbol j
         const int nv = (K - k0) < 16 ? (K - k0) : 16;
         const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < 16);
@@ -476,7 +505,7 @@ template <int BF, int FLAGS, bool ALIGNED>
 __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                             uint32_t amp_thr, RxDeferred& rd,
                                             unsigned long long* words, uint8_t* out_row,
-                                            int out_stride) {
+                                            int out_stride, int32_t* margins, int32_t mstride) {
     constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
     const int lane = fr.lane;
     const int shift = byte0 & 15;
@@ -527,7 +556,8 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
 #pragma unroll
         for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
         fr.next += 5;
-        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, rd, words, out_row, out_stride);
+        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, rd, words, out_row, out_stride,
+                                      margins, mstride);
         if (rd.st.phase == 2) break;
     }
 }
@@ -537,7 +567,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   uint8_t* lds, int lane, RxState& st,
                                                   uint8_t* out_row, int out_stride, int& ci_out,
                                                   int32_t& n_sym_out,
-                                                  unsigned long long* stamps = nullptr) {
+                                                  unsigned long long* stamps = nullptr,
+                                                  int32_t* margins = nullptr, int32_t mstride = 0) {
     constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
@@ -578,8 +609,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
     RxDeferred rd;
     rxd_init(rd);
-    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride);
-    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride);
+    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     rxd_finish<PS>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released

@@ -81,12 +81,17 @@ __device__ __forceinline__ uint32_t limit_pair_biased(uint32_t x) {
     return (__builtin_bit_cast(uint32_t, nn) & kBias) | __builtin_bit_cast(uint32_t, ps);
 }
 
-// Hamming(7,4) syndrome decode ref:145-151; bit t of cw = received bit t.
-__device__ __forceinline__ uint32_t hamming_nibble(uint32_t cw) {
+// Hamming(7,4) syndrome (error position, 0 = clean) ref:146-147; bit t of cw = received bit t.
+__device__ __forceinline__ uint32_t hamming_syndrome(uint32_t cw) {
     uint32_t s0 = __popc(cw & 0x55u) & 1u;   // parity row 1010101 (ref:126)
     uint32_t s1 = __popc(cw & 0x66u) & 1u;   // parity row 0110011 (ref:127)
     uint32_t s2 = __popc(cw & 0x78u) & 1u;   // parity row 0001111 (ref:128)
-    uint32_t pos = s2 * 4u + s1 * 2u + s0;   // ref:147
+    return s2 * 4u + s1 * 2u + s0;           // ref:147
+}
+
+// Hamming(7,4) syndrome decode ref:145-151; bit t of cw = received bit t.
+__device__ __forceinline__ uint32_t hamming_nibble(uint32_t cw) {
+    uint32_t pos = hamming_syndrome(cw);
     if (pos) cw ^= 1u << (pos - 1u);         // ref:149-150
     return (((cw >> 2) & 1u) << 3) | (((cw >> 4) & 1u) << 2) | (((cw >> 5) & 1u) << 1) |
            ((cw >> 6) & 1u);                 // ref:151
@@ -102,6 +107,7 @@ struct RxState {
     int32_t term_sym; // symbol index after the terminator (ref:368), -1 = none
     uint32_t pend;    // coded bits not yet forming a byte (< 14 of them)
     int npend;
+    int32_t corrected; // codewords decoded so far whose syndrome was non-zero (soft output)
 };
 
 // Training part (ref:361-366, 386-390).  bits: bit j = decision of symbol k0+j (j < nv).
@@ -162,6 +168,16 @@ __device__ __forceinline__ void rx_data(RxState& st, uint64_t bits, uint64_t amp
         const uint32_t byte = (hamming_nibble(c & 127u) << 4) | hamming_nibble(c >> 7);  // ref:393-399
         const int pos = st.nbytes + lane;
         if (pos < out_stride) out_row[pos] = (uint8_t)byte;
+    }
+    {   // soft output: corrected codewords among the 2*nb just decoded
+        uint32_t cc = 0;
+        if (lane < nb) {
+            const int o = 14 * lane;
+            uint32_t c = (uint32_t)(lo >> o);
+            if (o > 50) c |= (uint32_t)(hi << (64 - o));
+            cc = (hamming_syndrome(c & 127u) != 0) + (hamming_syndrome((c >> 7) & 127u) != 0);
+        }
+        st.corrected += (int32_t)__popcll(__ballot(cc >= 1)) + (int32_t)__popcll(__ballot(cc >= 2));
     }
     st.nbytes += nb;
     const int used = 14 * nb;           // <= 70
@@ -401,7 +417,9 @@ __device__ __forceinline__ void demod_symbols(const int16_t* xs, int32_t len, in
 __device__ __forceinline__ void demod_symbols_generic(const int16_t* xs, int32_t len, int ci,
                                                       int bf, int32_t amp_end, uint8_t* lds,
                                                       int lane, RxState& st, uint8_t* out_row,
-                                                      int out_stride, int32_t& n_sym_out) {
+                                                      int out_stride, int32_t& n_sym_out,
+                                                      int32_t* margins = nullptr,
+                                                      int32_t margin_stride = 0) {
     const int q = bf >> 2, h = bf >> 1;
     const int sym_b = bf * 2;
     int spr = (kWaveLds - 16) / sym_b;
@@ -434,11 +452,14 @@ __device__ __forceinline__ void demod_symbols_generic(const int16_t* xs, int32_t
             space += (uint32_t)(ts > a ? ts - a : a - ts);
             amp += (uint32_t)(x < 0 ? -x : x);
         }
-        const bool bit = div_exact(mark, (uint32_t)bf, rcp_bf) < div_exact(space, (uint32_t)bf, rcp_bf);
+        const uint32_t md = div_exact(mark, (uint32_t)bf, rcp_bf), sd = div_exact(space, (uint32_t)bf, rcp_bf);
+        const bool bit = md < sd;
         const bool loud = amp >= amp_thr;
         const uint64_t bmask = __ballot(bit && lane < spr);
         const uint64_t amask = __ballot(loud && lane < spr);
         const int k0 = r * spr;
+        if (margins && lane < spr && k0 + lane < K && k0 + lane < margin_stride)
+            margins[k0 + lane] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < spr ? (K - k0) : spr;
         // all lanes must have finished reading before the next round overwrites the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -486,17 +507,18 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     }
     RxState st;
     st.phase = 0; st.hist = 0; st.nbits = 0; st.nbytes = 0; st.term_sym = -1; st.pend = 0;
-    st.npend = 0;
+    st.npend = 0; st.corrected = 0;
     int32_t n_sym = 0;
+    int32_t* margins = a.out_margins ? a.out_margins + (int64_t)s * a.margin_stride : nullptr;
     int ci = 0;
     bool done = false;
     if constexpr (FAST) {   // single-pass ring kernel for the common bauds (afsk_demod_fast.h)
         unsigned long long* stamps = (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr;
         done = true;
         switch (bf) {
-            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
-            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
-            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps); break;
+            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             default:  done = false; break;
         }
     }
@@ -507,7 +529,9 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
         // (their values were consumed), so the DMA writes below cannot overtake them.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (FAST) {
-            demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym);
+            demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym,
+                                  margins, a.margin_stride);
+            if (st.npend >= 7) st.corrected += hamming_syndrome(st.pend & 127u) != 0;   // odd last codeword
         } else {
             switch (bf) {
                 case 40:  demod_symbols<40, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
@@ -524,6 +548,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
         a.out_clock_idx[s] = ci;
         a.out_term_frame[s] = ci + term_sym * bf;
         a.out_status[s] = st.nbits == 0 ? 2 : 0;   // ref:422-424
+        if (a.out_corrected) a.out_corrected[s] = st.corrected;
     }
 }
 

@@ -20,6 +20,10 @@ struct DemodArgs {
     int32_t* out_term_frame;
     int32_t* out_status;
     unsigned long long* debug_stamps = nullptr;   // diagnostics only (tools/kbench): 4 x u64 per stream
+    // optional soft outputs (afsk_demod_batch_ex); null = not wanted
+    int32_t* out_corrected = nullptr;             // [n] codewords with a non-zero Hamming syndrome
+    int32_t* out_margins = nullptr;               // [n, margin_stride] space_diff - mark_diff per symbol
+    int32_t margin_stride = 0;
 };
 
 struct ModulateArgs {

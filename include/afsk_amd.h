@@ -88,6 +88,28 @@ int afsk_demod_batch(const int16_t *samples, const int64_t *stream_offset,
                      void *hip_stream);
 
 /*
+ * afsk_demod_batch plus two optional soft outputs (either may be NULL), for callers that
+ * want link-quality figures without a second pass over the samples.  Both are values the
+ * reference computes and discards:
+ *
+ *  out_corrected  [n] codewords of ECC.decode's input (floor(nbits/7) of them, :156-157) whose
+ *                 syndrome (:146-147) was non-zero, i.e. single-bit corrections applied
+ *  out_margins    [n, margin_stride] per demodulated symbol k (sample clock_idx + k*bf),
+ *                 space_diff - mark_diff of __decodeBit (:348-349): > 0 decodes as 1, <= 0
+ *                 as 0 (:350-351).  Written for the symbols the reference demodulated:
+ *                 k < (term_frame - clock_idx)/bf + nbits when a terminator was found, else
+ *                 every k with clock_idx + k*bf < len - bf; entries past that (and past
+ *                 margin_stride) are unspecified/not written.
+ */
+int afsk_demod_batch_ex(const int16_t *samples, const int64_t *stream_offset,
+                        const int32_t *stream_len, const int32_t *bit_frames,
+                        int32_t amp_end_threshold, int32_t n_streams, uint8_t *out_bytes,
+                        int32_t out_stride, int32_t *out_nbytes, int32_t *out_nbits,
+                        int32_t *out_clock_idx, int32_t *out_term_frame, int32_t *out_status,
+                        int32_t *out_corrected, int32_t *out_margins, int32_t margin_stride,
+                        void *hip_stream);
+
+/*
  * Same operation on HOST buffers: allocates device scratch, copies in, runs the
  * HIP kernel, copies out, synchronises.  This is the PCIe-inclusive convenience
  * path a single Receiver.load() uses; it is not the benchmarked entry.

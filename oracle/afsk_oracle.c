@@ -115,6 +115,18 @@ int afsk_o_decode_bit(const int16_t *chunk, int bit_frames, const int16_t *mark_
     return mark_diff < space_diff ? 1 : 0;                          /* ref:348-351 */
 }
 
+/* ref:342-351 again, also reporting space_diff - mark_diff (values the reference computes at
+ * :346-347 and discards); the decision is unchanged: 1 iff mark_diff < space_diff. */
+static int decode_bit_soft(const int16_t *chunk, int bit_frames, const int16_t *mark_tone,
+                           const int16_t *space_tone, int32_t *margin) {
+    int16_t amp[SAMPLE_RATE];
+    afsk_o_amplify(chunk, bit_frames, amp);
+    int mark_diff = afsk_o_get_diff(mark_tone, amp, bit_frames);
+    int space_diff = afsk_o_get_diff(space_tone, amp, bit_frames);
+    if (margin) *margin = space_diff - mark_diff;
+    return mark_diff < space_diff ? 1 : 0;
+}
+
 /* ref:386-390 sliding 4-slot window, true when it reads 1,0,0,0. */
 static int scan_training(int seq[4], int current) {
     for (int i = 1; i < 4; i++) seq[i - 1] = seq[i];
@@ -146,7 +158,7 @@ static int build_templates_baud(int baud, struct templates *t) {
 static int64_t decode_bits_tpl(const int16_t *frames, int64_t len, int bit_frames,
                                const struct templates *t, int amp_end_threshold,
                                uint8_t *bits_out, int64_t bits_cap, int32_t *clock_idx,
-                               int64_t *term_frame) {
+                               int64_t *term_frame, int32_t *margins, int64_t margin_cap) {
     int ci = afsk_o_recover_clock_index(frames, len, bit_frames, t->training, t->training_len);
     if (clock_idx) *clock_idx = ci < -1 ? -1 : ci;
     if (term_frame) *term_frame = -1;
@@ -158,9 +170,12 @@ static int64_t decode_bits_tpl(const int16_t *frames, int64_t len, int bit_frame
     int training_bits[4] = {0, 0, 0, 0};                          /* ref:361 */
     while (i < len - bit_frames) {                                /* ref:362 */
         const int16_t *chunk = frames + i;                        /* ref:363 */
+        int64_t k = (i - ci) / bit_frames;                        /* symbol number (soft output) */
+        int32_t m;
         i += bit_frames;                                          /* ref:364 */
-        if (scan_training(training_bits,
-                          afsk_o_decode_bit(chunk, bit_frames, t->mark, t->space))) /* ref:365 */
+        int b = decode_bit_soft(chunk, bit_frames, t->mark, t->space, &m);
+        if (margins && k < margin_cap) margins[k] = m;
+        if (scan_training(training_bits, b))                      /* ref:365 */
             break;
     }
     if (term_frame) *term_frame = i;                              /* ref:368 */
@@ -169,7 +184,10 @@ static int64_t decode_bits_tpl(const int16_t *frames, int64_t len, int bit_frame
         const int16_t *chunk = frames + i;                        /* ref:373 */
         if (afsk_o_get_amplitude(chunk, bit_frames) < amp_end_threshold) break; /* ref:375-376 */
         if (nbits >= bits_cap) return AFSK_O_ERR_CAPACITY;
-        bits_out[nbits++] = (uint8_t)afsk_o_decode_bit(chunk, bit_frames, t->mark, t->space);
+        int64_t k = (i - ci) / bit_frames;
+        int32_t m;
+        bits_out[nbits++] = (uint8_t)decode_bit_soft(chunk, bit_frames, t->mark, t->space, &m);
+        if (margins && k < margin_cap) margins[k] = m;
         i += bit_frames;                                          /* ref:377-378 */
     }
     return nbits;
@@ -183,7 +201,7 @@ int64_t afsk_o_decode_bits(const int16_t *frames, int64_t len, int baud, int amp
     if (rc < 0) return rc;
     int bit_frames = (int)((double)SAMPLE_RATE / (double)baud);   /* ref:277 */
     int64_t n = decode_bits_tpl(frames, len, bit_frames, &t, amp_end_threshold, bits_out,
-                                bits_cap, clock_idx, term_frame);
+                                bits_cap, clock_idx, term_frame, NULL, 0);
     free(t.space);
     return n;
 }
@@ -228,6 +246,21 @@ int64_t afsk_o_ecc_decode(const uint8_t *bits, int64_t n, uint8_t *out) {
         out[o++] = (uint8_t)r[6];
     }
     return o;
+}
+
+/* Number of codewords ECC.decode (ref:154-163) would correct: syndromes != 0 at ref:147-148. */
+int64_t afsk_o_ecc_corrected(const uint8_t *bits, int64_t n) {
+    int64_t count = 0;
+    for (int64_t i = 0; i < n - 6; i += 7) {
+        int syn[3];
+        for (int a = 0; a < 3; a++) {
+            int acc = 0;
+            for (int j = 0; j < 7; j++) acc += M_PARITY[a][j] * (bits[i + j] ? 1 : 0);
+            syn[a] = acc % 2;
+        }
+        if (syn[2] * 4 + syn[1] * 2 + syn[0] != 0) count++;
+    }
+    return count;
 }
 
 /* ref:393-399 MSB-first, trailing bits dropped. */
@@ -384,6 +417,16 @@ int afsk_o_demod_stream(const int16_t *frames, int64_t len, int bit_frames, int 
                         uint8_t *out_bytes, int32_t out_cap, int32_t *out_nbytes,
                         int32_t *out_nbits, int32_t *out_clock_idx, int32_t *out_term_frame,
                         int32_t *out_status) {
+    return afsk_o_demod_stream_ex(frames, len, bit_frames, amp_end_threshold, out_bytes, out_cap,
+                                  out_nbytes, out_nbits, out_clock_idx, out_term_frame,
+                                  out_status, NULL, NULL, 0);
+}
+
+int afsk_o_demod_stream_ex(const int16_t *frames, int64_t len, int bit_frames,
+                           int amp_end_threshold, uint8_t *out_bytes, int32_t out_cap,
+                           int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
+                           int32_t *out_term_frame, int32_t *out_status, int32_t *out_corrected,
+                           int32_t *out_margins, int32_t margin_cap) {
     if (bit_frames <= 0 || bit_frames % 4 != 0 || bit_frames * 2 >= SYNC_WINDOW)
         return AFSK_O_ERR_INVALID_BAUD;
     struct templates t;
@@ -403,7 +446,7 @@ int afsk_o_demod_stream(const int16_t *frames, int64_t len, int bit_frames, int 
     int32_t ci = -1;
     int64_t term = -1;
     int64_t nbits = decode_bits_tpl(frames, len, bit_frames, &t, amp_end_threshold, bits,
-                                    cap_bits, &ci, &term);
+                                    cap_bits, &ci, &term, out_margins, margin_cap);
     int rc = AFSK_O_OK;
     if (nbits < 0) {
         rc = (int)nbits;
@@ -414,6 +457,7 @@ int afsk_o_demod_stream(const int16_t *frames, int64_t len, int bit_frames, int 
         int64_t ncopy = nbytes < out_cap ? nbytes : out_cap;
         if (out_bytes && ncopy > 0) memcpy(out_bytes, bytes, (size_t)ncopy);
         free(bytes);
+        if (out_corrected) *out_corrected = (int32_t)afsk_o_ecc_corrected(bits, nbits);
         *out_nbytes = (int32_t)nbytes;
         *out_nbits = (int32_t)nbits;
         *out_clock_idx = ci;

@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         L.afsk_o_gate_stream.restype = C.c_int32
         L.afsk_o_demod_batch.argtypes = [i16p, i64p, i32p, i32p, C.c_int32, C.c_int32, u8p,
                                          C.c_int32, i32p, i32p, i32p, i32p, i32p, C.c_int32]
+        L.afsk_o_demod_stream_ex.argtypes = [i16p, C.c_int64, C.c_int, C.c_int, u8p, C.c_int32,
+                                             i32p, i32p, i32p, i32p, i32p, i32p, i32p, C.c_int32]
         L.afsk_o_modulate_batch.argtypes = [u8p, C.c_int32, i32p, i32p, i32p, i64p, i32p,
                                             C.c_int32, C.c_int32, i16p]
         _lib = L
@@ -243,6 +245,34 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         _p(out["nbytes"], C.c_int32), _p(out["nbits"], C.c_int32),
         _p(out["clock_idx"], C.c_int32), _p(out["term_frame"], C.c_int32),
         _p(out["status"], C.c_int32), int(n_threads)))
+    return out
+
+
+def demod_batch_soft(samples, stream_offset, stream_len, bit_frames,
+                     amp_end_threshold: int = 14000, out_stride: int = 128,
+                     margin_stride: int = 2400):
+    """demod_batch plus the soft outputs of afsk_demod_batch_ex (corrected, margins);
+    ``n_symbols`` = how many leading margins of each row the reference demodulated."""
+    s = _i16(samples).reshape(-1)
+    off = np.ascontiguousarray(stream_offset, dtype=np.int64)
+    ln = np.ascontiguousarray(stream_len, dtype=np.int32)
+    bf = np.ascontiguousarray(bit_frames, dtype=np.int32)
+    n = off.size
+    out = {k: np.zeros(n, dtype=np.int32)
+           for k in ("nbytes", "nbits", "clock_idx", "term_frame", "status", "corrected")}
+    out["bytes"] = np.zeros((n, out_stride), dtype=np.uint8)
+    out["margins"] = np.zeros((n, margin_stride), dtype=np.int32)
+    one = [np.zeros(1, dtype=np.int32) for _ in range(6)]
+    for i in range(n):
+        fr = np.ascontiguousarray(s[off[i]: off[i] + ln[i]])
+        _check(lib().afsk_o_demod_stream_ex(
+            _p(fr, C.c_int16), fr.size, int(bf[i]), int(amp_end_threshold),
+            _p(out["bytes"][i], C.c_uint8), out_stride, *[_p(a, C.c_int32) for a in one],
+            _p(out["margins"][i], C.c_int32), margin_stride))
+        for k, a in zip(("nbytes", "nbits", "clock_idx", "term_frame", "status", "corrected"), one):
+            out[k][i] = a[0]
+    ci, tf = out["clock_idx"].astype(np.int64), out["term_frame"].astype(np.int64)
+    out["n_symbols"] = np.where(ci >= 0, (tf - ci) // bf + out["nbits"], 0)
     return out
 
 

@@ -85,8 +85,32 @@ def ref_decode(frames: list[int], baud: int, amp_end: int = 14000):
     ref.LOG_LEVEL = 0
     r = ref.Receiver(baud, 18000, amp_end)
     buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
-        bits = r._Receiver__decodeBits(list(frames))
+    # soft values the reference computes and discards: record the getDiff results of
+    # __decodeBit (:346-347, the calls on one-symbol chunks: mark first, then space) and the
+    # syndromes of ECC.__decodeNibble (:146, the 3-row products)
+    bit_frames = int(48000 / baud)
+    diffs, syndromes = [], []
+    real_diff, real_mul = ref.Waveforms.getDiff, ref.ECC._ECC__multiply
+
+    def rec_diff(a, b):
+        d = real_diff(a, b)
+        if len(a) == bit_frames:
+            diffs.append(d)
+        return d
+
+    def rec_mul(a, b):
+        v = real_mul(a, b)
+        if len(a) == 3:
+            syndromes.append(v[2] * 4 + v[1] * 2 + v[0])
+        return v
+
+    ref.Waveforms.getDiff = rec_diff
+    try:
+        with contextlib.redirect_stdout(buf):
+            bits = r._Receiver__decodeBits(list(frames))
+    finally:
+        ref.Waveforms.getDiff = real_diff
+    margins = [diffs[i + 1] - diffs[i] for i in range(0, len(diffs) - 1, 2)]   # space - mark
     log = buf.getvalue()
     m_ci = re.search(r"Recovered clock\. \(frame (\d+)\)", log)
     m_tf = re.search(r"Training sequence terminated on frame (\d+)", log)
@@ -95,10 +119,18 @@ def ref_decode(frames: list[int], baud: int, amp_end: int = 14000):
     if bits == "":
         data = b""
     else:
-        data = r._Receiver__bitsToBytes(ref.ECC.decode(bits))
+        ref.ECC._ECC__multiply = rec_mul
+        try:
+            data = r._Receiver__bitsToBytes(ref.ECC.decode(bits))
+        finally:
+            ref.ECC._ECC__multiply = real_mul
     ref.LOG_LEVEL = 5
     return {"clock_idx": ci, "term_frame": tf, "nbits": len(bits), "bits": bits,
-            "bytes_hex": data.hex(), "nbytes": len(data)}
+            "bytes_hex": data.hex(), "nbytes": len(data),
+            "soft": {"n_symbols": len(margins), "corrected": sum(1 for v in syndromes if v),
+                     "margins_head": margins[:24],
+                     "margins_sha256": hashlib.sha256(
+                         np.asarray(margins, dtype="<i4").tobytes()).hexdigest()}}
 
 
 def main():

@@ -89,6 +89,78 @@ def test_golden_cases_device_entry(golden, torch_cuda):
         assert got == (c["clock_idx"], c["term_frame"], c["nbits"], c["bytes_hex"]), c["tag"]
 
 
+def soft_demod(torch, flat, off, ln, bf, amp_end, stride, mstride):
+    dev = "cuda:0"
+    x = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int16)).to(dev)
+    o = torch.from_numpy(np.ascontiguousarray(off, dtype=np.int64)).to(dev)
+    l = torch.from_numpy(np.ascontiguousarray(ln, dtype=np.int32)).to(dev)
+    res = batch.demod_batch(x, o, l, np.asarray(bf, np.int32), amp_end, out_stride=stride,
+                            diagnostics=True, margin_stride=mstride)
+    torch.cuda.synchronize()
+    nsym = res.symbols_demodulated(np.asarray(bf, np.int64)).cpu().numpy()
+    return res.cpu(), res.corrected.cpu().numpy(), res.margins.cpu().numpy(), nsym
+
+
+def test_soft_outputs_golden_cases(golden, torch_cuda):
+    """afsk_demod_batch_ex: corrected-codeword counts and per-symbol margins against the values
+    recorded from inside the reference (make_golden.py, ``soft``), every decode case, one
+    ragged mixed-baud launch per threshold; the hard outputs must not change."""
+    import hashlib
+    cases = golden["decode_cases"]
+    xs = [build_input(c) for c in cases]
+    for amp_end in sorted({c["amp_end"] for c in cases}):
+        idx = [i for i, c in enumerate(cases) if c["amp_end"] == amp_end]
+        ln = np.array([len(xs[i]) for i in idx], np.int32)
+        off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+        bf = np.array([48000 // cases[i]["baud"] for i in idx], np.int32)
+        res, corr, marg, nsym = soft_demod(torch_cuda, np.concatenate([xs[i] for i in idx]), off,
+                                           ln, bf, amp_end, 160, 4000)
+        pl = res.payloads()
+        for j, i in enumerate(idx):
+            c = cases[i]
+            got = (int(res.clock_idx[j]), int(res.term_frame[j]), int(res.nbits[j]), pl[j].hex())
+            assert got == (c["clock_idx"], c["term_frame"], c["nbits"], c["bytes_hex"]), c["tag"]
+            if c["clock_idx"] < 0:
+                continue
+            soft = c["soft"]
+            assert int(nsym[j]) == soft["n_symbols"], c["tag"]
+            m = marg[j, : soft["n_symbols"]]
+            assert m[:24].tolist() == soft["margins_head"], c["tag"]
+            assert hashlib.sha256(m.astype("<i4").tobytes()).hexdigest() == soft["margins_sha256"], c["tag"]
+            assert int(corr[j]) == soft["corrected"], c["tag"]
+
+
+def test_soft_outputs_noise_vs_oracle(torch_cuda):
+    """Soft outputs on noisy 1 s streams at every fast-path baud plus two generic ones; the
+    margins row is compared over exactly the symbols the reference demodulated, and a narrow
+    margin_stride truncates rows without touching the neighbours."""
+    torch = torch_cuda
+    for bauds, snrs in (((1200,), [20, 8, 5, 3, 0]), ((2400,), [12, 6, 2]), ((300,), [12, 6, 2]),
+                        ((600, 4000), [10, 4]), ((300, 1200, 2400, 600), [9, 5])):
+        n = 32 * len(snrs)
+        b = synth_batch(torch, n, bauds, seed=77 + len(snrs) + bauds[0], snr_db=np.repeat(snrs, 32),
+                        payload_len=6 if min(bauds) < 1200 else 30)
+        stride = batch.out_stride_for(b["total"], int(b["h_bf"].min()))
+        ms = b["total"] // int(b["h_bf"].min())
+        host = b["samples"].cpu().numpy()
+        want = O.demod_batch_soft(host, b["h_off"], b["h_ln"], b["h_bf"], 14000, out_stride=stride,
+                                  margin_stride=ms)
+        for mstride in (ms, 100):
+            res = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000,
+                                    out_stride=stride, diagnostics=True, margin_stride=mstride)
+            torch.cuda.synchronize()
+            assert_same(res.cpu(), want, f"soft {bauds}")
+            corr, marg = res.corrected.cpu().numpy(), res.margins.cpu().numpy()
+            nsym = res.symbols_demodulated(b["bf"]).cpu().numpy()
+            assert (nsym == want["n_symbols"]).all()
+            assert (corr == want["corrected"]).all(), np.nonzero(corr != want["corrected"])[0][:8]
+            col = np.arange(mstride)[None, :]
+            mask = col < np.minimum(nsym, mstride)[:, None]
+            bad = np.nonzero(((marg != want["margins"][:, :mstride]) & mask).any(axis=1))[0]
+            assert bad.size == 0, (bauds, mstride, bad[:8])
+        assert want["corrected"].max() > 0
+
+
 def test_receiver_load_readme_roundtrip(golden, torch_cuda, tmp_path):
     """README.md:47-66 assertion through the drop-in API (Transmitter.save -> Receiver.load)."""
     afskmodem.LOG_LEVEL = 5

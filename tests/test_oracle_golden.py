@@ -105,6 +105,26 @@ def test_demod_batch_matches_cases(golden):
             assert out["status"][i] == want, c["tag"]
 
 
+def test_soft_outputs_match_reference_internals(golden):
+    """Row f4: the soft outputs are values the reference computes and discards -- the two
+    getDiff results of __decodeBit (:346-347) and ECC.__decodeNibble's syndrome (:146-147) --
+    recorded from the reference by make_golden.py for every decode case."""
+    for c in golden["decode_cases"]:
+        x = build_input(c)
+        out = O.demod_batch_soft(x, [0], [len(x)], [48000 // c["baud"]], c["amp_end"],
+                                 out_stride=160, margin_stride=4000)
+        soft = c["soft"]
+        ns = int(out["n_symbols"][0])
+        assert ns == soft["n_symbols"], c["tag"]
+        assert ns <= 4000
+        m = out["margins"][0, :ns]
+        assert m[:24].tolist() == soft["margins_head"], c["tag"]
+        assert hashlib.sha256(m.astype("<i4").tobytes()).hexdigest() == soft["margins_sha256"], c["tag"]
+        assert int(out["corrected"][0]) == soft["corrected"], c["tag"]
+        assert out["bytes"][0, : c["nbytes"]].tobytes().hex() == c["bytes_hex"], c["tag"]
+    assert sum(c["soft"]["corrected"] for c in golden["decode_cases"]) > 100   # exercised
+
+
 def test_readme_roundtrip(golden):
     w = O.wav_convert(O.get_frames("Héellóo World!".encode(), 1200))
     assert O.load_frames(w, 1200).decode("utf-8") == golden["readme_roundtrip"]
