@@ -59,15 +59,82 @@ __device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym,
     return train ? ((S & 1u) == 0) : (term ? (t == 0u) : data_bit);
 }
 
+constexpr int kQWords = kModChunk / 32 + 16;                  // quarter-symbol bitmap of one block
+
+constexpr uint32_t kHi2 = 0x7FFF7FFFu, kLo2 = 0x80008000u;    // two samples at +32767 / -32768
+
+// 8 samples of a block that lies entirely inside the tones.  A tone is constant over a quarter
+// symbol (q = bf/4 frames: space = hi,hi,lo,lo ref:68-77, mark = hi,lo,hi,lo ref:80-85), so the
+// block keeps ONE bit per quarter symbol in LDS (qb, bit r = quarter 4*Sb + r is high) and a
+// store needs the quarter of its first frame (one exact float division: x0 < 2^14) plus
+//   q >= 8 : at most one quarter boundary inside the 8 frames -> compare against its position
+//   q <  8 : the quarter offset of every frame by a 16-bit reciprocal multiply (exact below 14)
+template <bool QUIRK, bool SMALLQ>
+__device__ __forceinline__ store16 tone_words(uint32_t x0, uint32_t q, float rcp_q, uint32_t mq,
+                                              const uint32_t* qb) {
+    const uint32_t Q0 = (uint32_t)(((float)x0 + 0.5f) * rcp_q);
+    const uint32_t r0 = x0 - Q0 * q;
+    const uint32_t bits = __builtin_amdgcn_alignbit(qb[(Q0 >> 5) + 1u], qb[Q0 >> 5], Q0 & 31u);
+    store16 w;
+    if constexpr (!SMALLQ) {
+        const uint32_t c = q - r0;                               // frames j < c are in quarter Q0
+        if constexpr (QUIRK) {                                   // out[2i] = out[2i+1] = frames[2i]
+            const uint32_t d0 = (bits & 1u) ? kHi2 : kLo2, d1 = (bits & 2u) ? kHi2 : kLo2;
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) w[d] = 2u * d < c ? d0 : d1;
+        } else {
+            const uint32_t l0 = (bits & 1u) ? 0x7FFFu : 0x8000u, l1 = (bits & 2u) ? 0x7FFFu : 0x8000u;
+            const uint32_t h0 = l0 << 16, h1 = l1 << 16;
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) w[d] = (2u * d < c ? l0 : l1) | (2u * d + 1u < c ? h0 : h1);
+        }
+    } else {
+        auto hi = [&](uint32_t j) -> bool {
+            const uint32_t dq = ((r0 + j) * mq) >> 16;           // (r0 + j) / q, r0 + j <= 13
+            return (bits >> dq) & 1u;
+        };
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) {
+            if constexpr (QUIRK) w[d] = hi(2u * d) ? kHi2 : kLo2;
+            else w[d] = (hi(2u * d) ? 0x7FFFu : 0x8000u) | (hi(2u * d + 1u) ? 0x7FFF0000u : 0x80000000u);
+        }
+    }
+    return w;
+}
+
+template <bool QUIRK, bool SMALLQ>
+__device__ __forceinline__ void tone_block(int16_t* dst0, uint32_t base, uint32_t len, uint32_t phb,
+                                           uint32_t q, const uint32_t* qb) {
+    const float rcp_q = 1.0f / (float)q;
+    const uint32_t mq = (65536u + q - 1u) / q;
+#pragma unroll
+    for (int it = 0; it < kModIters; it++) {
+        const uint32_t local = ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
+        const uint32_t p0 = base + local;
+        if (p0 >= len) break;
+        const store16 w = tone_words<QUIRK, SMALLQ>(phb + local, q, rcp_q, mq, qb);
+        int16_t* dst = dst0 + p0;
+        if (p0 + 8u <= len) {
+            *reinterpret_cast<store16*>(dst) = w;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++)
+                if (p0 + j < len) dst[j] = (int16_t)(w[j >> 1] >> (16u * (j & 1u)));
+        }
+    }
+}
+
 // One block = 8192 consecutive output samples of one stream; one thread = 4 x (8 samples =
-// one 16-byte store).  Per block, once: the per-stream scalars, the payload window (LDS) and a
-// bitmap of the tone kind of every symbol the block touches (one ballot per 64 symbols).  Per
-// store: three bitmap bits (a store touches at most 3 symbols, bf >= 4) and branch-free
-// phase arithmetic; positions fit in 32 bits (stream_len < 2^30), no division in the loop.
+// one 16-byte store).  Blocks past the tones store zeros; blocks inside the tones build, once,
+// the payload window, a bitmap of the tone kind of every symbol they touch (one ballot per 64
+// symbols) and from it the quarter-symbol bitmap tone_words() reads.  Only the block holding
+// the tones/silence boundary (and bit_frames that are no multiple of 4) takes the general
+// per-frame path below.  Positions fit in 32 bits (stream_len < 2^30).
 __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     __shared__ uint8_t win[kModThreads];
-    // tone kind (1 = mark) of every symbol the block touches: at most 8192/4 + 2 symbols
+    // tone kind (1 = mark) of every symbol the block touches: at most 8192/4 + 3 symbols
     __shared__ unsigned long long kinds[kModChunk / 4 / 64 + 2];
+    __shared__ uint32_t qbits[kQWords];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const uint32_t len = (uint32_t)a.stream_len[s];
@@ -87,6 +154,22 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     const uint32_t lim = n_tones < n_out ? n_tones : n_out;    // frames at or past this are zero
     int16_t* dst0 = a.samples + a.stream_offset[s];
 
+    if (base >= lim) {                                         // tail silence ref:468 + padding
+#pragma unroll
+        for (int it = 0; it < kModIters; it++) {
+            const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
+            if (p0 >= len) break;
+            int16_t* dst = dst0 + p0;
+            if (p0 + 8u <= len) {
+                *reinterpret_cast<store16*>(dst) = store16{0u, 0u, 0u, 0u};
+            } else {
+                for (uint32_t j = 0; j < 8u; j++)
+                    if (p0 + j < len) dst[j] = 0;
+            }
+        }
+        return;
+    }
+
     // payload window of this block: the block spans < 8192 / (14 * bf) + 2 <= 148 bytes
     const uint32_t data0 = n_train_sym + 4u;
     const uint32_t Sb = base / bf;
@@ -97,9 +180,9 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     }
     __syncthreads();
     // Kind bitmap: bit r = symbol Sb + r.  Each wave ballots 64 consecutive symbols per pass.
+    const uint32_t last = (base + kModChunk - 1u) / bf + 2u;              // exclusive upper bound + slack
+    const uint32_t nsym_blk = last - Sb + 1u;
     {
-        const uint32_t last = (base + kModChunk - 1u) / bf + 2u;          // exclusive upper bound + slack
-        const uint32_t nsym_blk = last - Sb + 1u;
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         for (uint32_t r0 = wave * 64u; r0 < nsym_blk; r0 += kModThreads) {
             const uint32_t S = Sb + r0 + lane;
@@ -109,10 +192,33 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
         }
     }
     __syncthreads();
-
-    // Symbol / phase of this thread's first store, then advanced by 2048 samples per iteration
-    // without further divisions: x < bf + 2048 (bf < 2048), so a float estimate + fix-up is exact.
     const uint32_t phb = base - Sb * bf;
+
+    if ((bf & 3u) == 0u && base + kModChunk + 8u <= lim) {      // block-uniform: all tones
+        // quarter bitmap: word w = symbols Sb + 8w .. 8w+7, 4 bits each: space 0b0011, mark 0b0101
+        const uint32_t nwords = (nsym_blk + 7u) >> 3;
+        for (uint32_t w = threadIdx.x; w <= nwords; w += kModThreads) {
+            uint32_t x = w < nwords ? (uint32_t)(kinds[w >> 3] >> ((w & 7u) * 8u)) & 0xFFu : 0u;
+            x = (x | (x << 12)) & 0x000F000Fu;                   // bit k -> bit 4k
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;
+            qbits[w] = 0x33333333u ^ (x * 6u);
+        }
+        __syncthreads();
+        const uint32_t q = bf >> 2;
+        if (a.wav_quirk) {
+            if (q >= 8u) tone_block<true, false>(dst0, base, len, phb, q, qbits);
+            else tone_block<true, true>(dst0, base, len, phb, q, qbits);
+        } else {
+            if (q >= 8u) tone_block<false, false>(dst0, base, len, phb, q, qbits);
+            else tone_block<false, true>(dst0, base, len, phb, q, qbits);
+        }
+        return;
+    }
+
+    // General path (the block that contains the end of the tones).  Symbol / phase of this
+    // thread's first store, then advanced by 2048 samples per iteration without further
+    // divisions: x < bf + 2048 (bf < 2048), so a float estimate + fix-up is exact.
     const float rcp_bf = 1.0f / (float)bf;
     auto divmod_small = [&](uint32_t x, uint32_t& q, uint32_t& r) {
         q = (uint32_t)((float)x * rcp_bf);
@@ -127,7 +233,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     uint32_t step_q, step_r;                                   // 2048 = step_q * bf + step_r
     divmod_small(2048u, step_q, step_r);
 
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < kModIters; it++) {
         const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
         if (p0 >= len) break;

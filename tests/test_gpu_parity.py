@@ -252,6 +252,46 @@ def test_modulator_and_noise_match_oracle(torch_cuda):
         assert np.array_equal(noisy[s], O.add_noise(clean[s], 14, s, int(b3["q"][s]))), s
 
 
+@pytest.mark.parametrize("wav_quirk", [True, False])
+def test_modulator_every_quarter_width(torch_cuda, wav_quirk):
+    """Modulator vs oracle over the bit_frames the reference can transmit (divisors of 48000
+    that are multiples of 4: quarter-symbol widths 1, 2, 3, 4, 5, 6 on the small-width path, 8 and
+    up on the one-boundary path, up to bit_frames 2000), long training so
+    most 8192-sample blocks are all-tone blocks, ragged lengths, odd 2-byte stream offsets,
+    empty and long payloads."""
+    torch = torch_cuda
+    dev = "cuda:0"
+    rng = np.random.default_rng(2024 + int(wav_quirk))
+    bfs = [4, 8, 12, 16, 20, 24, 32, 40, 48, 60, 64, 80, 96, 100, 120, 128, 160, 192, 240, 300, 400,
+           480, 640, 1000, 1500, 2000]
+    bf = np.array([b for b in bfs for _ in range(3)], np.int32)
+    n = bf.size
+    ln = rng.integers(1, 60000, n).astype(np.int32)
+    ln[::7] = 8192 * rng.integers(1, 6, ln[::7].size)          # exact block multiples too
+    gaps = rng.integers(0, 5, n)
+    off = np.concatenate([[3], 3 + np.cumsum(ln[:-1] + gaps[:-1])]).astype(np.int64)
+    total = int(off[-1] + ln[-1] + 8)
+    plen = rng.integers(0, 41, n).astype(np.int32)
+    plen[:4] = (0, 40, 1, 0)
+    ts = rng.integers(1, 3000, n).astype(np.int32)
+    ts[bf > 64] = rng.integers(1, 40, int((bf > 64).sum()))
+    payload = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    samples = torch.full((total,), 12345, dtype=torch.int16, device=dev)
+    batch.modulate_batch(t(payload), t(plen), t(bf), t(ts), t(off), t(ln), int(ln.max()), samples,
+                         wav_quirk)
+    torch.cuda.synchronize()
+    got = samples.cpu().numpy()
+    want = O.modulate_batch(payload, plen, bf, ts, off, ln, total, wav_quirk)
+    covered = np.zeros(total, bool)
+    for i in range(n):
+        sl = slice(int(off[i]), int(off[i] + ln[i]))
+        covered[sl] = True
+        bad = np.nonzero(got[sl] != want[sl])[0]
+        assert bad.size == 0, (int(bf[i]), int(ln[i]), int(ts[i]), int(plen[i]), bad[:6])
+    assert (got[~covered] == 12345).all()                        # nothing written outside the streams
+
+
 @pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])
 def test_clean_batches_vs_oracle(torch_cuda, n, bauds):
     """Config #2 / #3 shapes at test size: every output equals the CPU oracle's, and the
