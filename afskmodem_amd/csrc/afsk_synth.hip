@@ -10,20 +10,13 @@
 // consecutive samples and stores them with one 16-byte store.
 #include "afsk_kernels.h"
 
+#include <type_traits>
+
 namespace afsk {
 
-struct pack8 { int16_t v[8]; };
 // 16 bytes to a 2-byte-aligned address with ONE global_store_dwordx4 (gfx950 stores are
 // alignment-agnostic; a packed struct made hipcc split the store in three).
 typedef uint32_t store16 __attribute__((ext_vector_type(4), aligned(2)));
-
-__device__ __forceinline__ void store_pack8(int16_t* dst, const pack8& v) {
-    store16 w;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        w[k] = (uint32_t)(uint16_t)v.v[2 * k] | ((uint32_t)(uint16_t)v.v[2 * k + 1] << 16);
-    *reinterpret_cast<store16*>(dst) = w;
-}
 
 // Symbol layout of the ideal frame list (ref:452-469), in symbols of bf frames:
 //   [0, 2*ts)            training cycles: mark, space, mark, space ...        ref:457-458
@@ -40,8 +33,9 @@ __device__ __forceinline__ uint32_t hamming_codeword(uint32_t nib) {
 }
 
 constexpr int kModThreads = 256;
-constexpr int kModIters = 4;                                   // 16-byte stores per thread
-constexpr int kModChunk = kModThreads * 8 * kModIters;         // samples per block (8192)
+constexpr int kModIters = 8;                                   // 16-byte stores per thread (product)
+constexpr int mod_chunk(int iters) { return kModThreads * 8 * iters; }   // samples per block
+constexpr int kWinBytes = 2 * kModThreads;                     // payload window of one block
 
 // Branch-free tone kind of symbol S (true = mark).  `win` is the block's payload window in
 // LDS: win[k] = payload[first_byte + k].
@@ -51,7 +45,7 @@ __device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym,
     const uint32_t b = t - 4u;                       // coded bit index (wraps before the data)
     const uint32_t cw = b / 7u;                      // nibble index
     const uint32_t pos = b - cw * 7u;
-    const uint32_t byte = win[((cw >> 1) - first_byte) & (kModThreads - 1)];
+    const uint32_t byte = win[((cw >> 1) - first_byte) & (kWinBytes - 1)];
     const uint32_t nib = (cw & 1u) ? (byte & 15u) : (byte >> 4);        // ref:446-450 MSB first
     const bool data_bit = ((hamming_codeword(nib) >> pos) & 1u) != 0;
     const bool train = S < n_train_sym;
@@ -59,7 +53,7 @@ __device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym,
     return train ? ((S & 1u) == 0) : (term ? (t == 0u) : data_bit);
 }
 
-constexpr int kQWords = kModChunk / 32 + 16;                  // quarter-symbol bitmap of one block
+constexpr int q_words(int iters) { return mod_chunk(iters) / 32 + 16; }   // quarter-symbol bitmap words
 
 constexpr uint32_t kHi2 = 0x7FFF7FFFu, kLo2 = 0x80008000u;    // two samples at +32767 / -32768
 
@@ -102,17 +96,23 @@ __device__ __forceinline__ store16 tone_words(uint32_t x0, uint32_t q, float rcp
     return w;
 }
 
-template <bool QUIRK, bool SMALLQ>
+// TAIL = the block contains the end of the tones: frames at or past `lim` are zero (lim is even
+// when bit_frames % 4 == 0, so whole dwords switch).
+template <int ITERS, bool QUIRK, bool SMALLQ, bool TAIL>
 __device__ __forceinline__ void tone_block(int16_t* dst0, uint32_t base, uint32_t len, uint32_t phb,
-                                           uint32_t q, const uint32_t* qb) {
+                                           uint32_t q, const uint32_t* qb, uint32_t lim) {
     const float rcp_q = 1.0f / (float)q;
     const uint32_t mq = (65536u + q - 1u) / q;
 #pragma unroll
-    for (int it = 0; it < kModIters; it++) {
+    for (int it = 0; it < ITERS; it++) {
         const uint32_t local = ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
         const uint32_t p0 = base + local;
         if (p0 >= len) break;
-        const store16 w = tone_words<QUIRK, SMALLQ>(phb + local, q, rcp_q, mq, qb);
+        store16 w = tone_words<QUIRK, SMALLQ>(phb + local, q, rcp_q, mq, qb);
+        if constexpr (TAIL) {
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) w[d] = p0 + 2u * d < lim ? w[d] : 0u;
+        }
         int16_t* dst = dst0 + p0;
         if (p0 + 8u <= len) {
             *reinterpret_cast<store16*>(dst) = w;
@@ -124,17 +124,19 @@ __device__ __forceinline__ void tone_block(int16_t* dst0, uint32_t base, uint32_
     }
 }
 
-// One block = 8192 consecutive output samples of one stream; one thread = 4 x (8 samples =
-// one 16-byte store).  Blocks past the tones store zeros; blocks inside the tones build, once,
-// the payload window, a bitmap of the tone kind of every symbol they touch (one ballot per 64
-// symbols) and from it the quarter-symbol bitmap tone_words() reads.  Only the block holding
-// the tones/silence boundary (and bit_frames that are no multiple of 4) takes the general
-// per-frame path below.  Positions fit in 32 bits (stream_len < 2^30).
-__global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
-    __shared__ uint8_t win[kModThreads];
-    // tone kind (1 = mark) of every symbol the block touches: at most 8192/4 + 3 symbols
+// One block = ITERS * 2048 consecutive output samples of one stream; one thread = ITERS x
+// (8 samples = one 16-byte store).  Blocks past the tones store zeros; the others build, once,
+// the payload window (skipped inside the training sequence), a bitmap of the tone kind of every
+// symbol they touch (one ballot per 64 symbols) and from it the quarter-symbol bitmap
+// tone_words() reads.  Positions fit in 32 bits (stream_len < 2^30).
+template <int ITERS>
+__global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a) {
+    constexpr int kModChunk = mod_chunk(ITERS);
+    static_assert(kModChunk / 56 + 4 <= kWinBytes, "payload window too small for the block");
+    __shared__ uint8_t win[kWinBytes];
+    // tone kind (1 = mark) of every symbol the block touches: at most chunk/4 + 3 symbols
     __shared__ unsigned long long kinds[kModChunk / 4 / 64 + 2];
-    __shared__ uint32_t qbits[kQWords];
+    __shared__ uint32_t qbits[q_words(ITERS)];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const uint32_t len = (uint32_t)a.stream_len[s];
@@ -151,12 +153,15 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     const uint64_t n_out64 = a.wav_quirk ? (n_frames64 & ~1ull) : n_frames64;
     const uint32_t n_tones = n_tones64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_tones64;
     const uint32_t n_out = n_out64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_out64;
-    const uint32_t lim = n_tones < n_out ? n_tones : n_out;    // frames at or past this are zero
+    // frames at or past lim are zero; a bit_frames outside the kernels' domain (not a positive
+    // multiple of 4, include/afsk_amd.h) yields an all-zero stream
+    const bool bf_ok = bf >= 4u && bf <= (1u << 20) && (bf & 3u) == 0u;   // negative wraps high
+    const uint32_t lim = bf_ok ? (n_tones < n_out ? n_tones : n_out) : 0u;
     int16_t* dst0 = a.samples + a.stream_offset[s];
 
     if (base >= lim) {                                         // tail silence ref:468 + padding
 #pragma unroll
-        for (int it = 0; it < kModIters; it++) {
+        for (int it = 0; it < ITERS; it++) {
             const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
             if (p0 >= len) break;
             int16_t* dst = dst0 + p0;
@@ -170,18 +175,21 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
         return;
     }
 
-    // payload window of this block: the block spans < 8192 / (14 * bf) + 2 <= 148 bytes
+    // payload window of this block: the block spans < chunk / (14 * bf) + 2 bytes
     const uint32_t data0 = n_train_sym + 4u;
     const uint32_t Sb = base / bf;
     const uint32_t first_byte = ((Sb > data0 ? Sb - data0 : 0u) / 7u) >> 1;
-    {
-        const uint32_t idx = first_byte + threadIdx.x;
-        win[threadIdx.x] = idx < plen ? payload[idx] : (uint8_t)0;
-    }
-    __syncthreads();
-    // Kind bitmap: bit r = symbol Sb + r.  Each wave ballots 64 consecutive symbols per pass.
     const uint32_t last = (base + kModChunk - 1u) / bf + 2u;              // exclusive upper bound + slack
     const uint32_t nsym_blk = last - Sb + 1u;
+    if (Sb + nsym_blk > data0) {                                           // block-uniform: data symbols
+#pragma unroll
+        for (uint32_t k = threadIdx.x; k < (uint32_t)kWinBytes; k += kModThreads) {
+            const uint32_t idx = first_byte + k;
+            win[k] = idx < plen ? payload[idx] : (uint8_t)0;
+        }
+        __syncthreads();
+    }
+    // Kind bitmap: bit r = symbol Sb + r.  Each wave ballots 64 consecutive symbols per pass.
     {
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         for (uint32_t r0 = wave * 64u; r0 < nsym_blk; r0 += kModThreads) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
     __syncthreads();
     const uint32_t phb = base - Sb * bf;
 
-    if ((bf & 3u) == 0u && base + kModChunk + 8u <= lim) {      // block-uniform: all tones
+    {
         // quarter bitmap: word w = symbols Sb + 8w .. 8w+7, 4 bits each: space 0b0011, mark 0b0101
         const uint32_t nwords = (nsym_blk + 7u) >> 3;
         for (uint32_t w = threadIdx.x; w <= nwords; w += kModThreads) {
@@ -206,74 +214,18 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel(ModulateArgs a) {
         }
         __syncthreads();
         const uint32_t q = bf >> 2;
-        if (a.wav_quirk) {
-            if (q >= 8u) tone_block<true, false>(dst0, base, len, phb, q, qbits);
-            else tone_block<true, true>(dst0, base, len, phb, q, qbits);
-        } else {
-            if (q >= 8u) tone_block<false, false>(dst0, base, len, phb, q, qbits);
-            else tone_block<false, true>(dst0, base, len, phb, q, qbits);
-        }
-        return;
-    }
-
-    // General path (the block that contains the end of the tones).  Symbol / phase of this
-    // thread's first store, then advanced by 2048 samples per iteration without further
-    // divisions: x < bf + 2048 (bf < 2048), so a float estimate + fix-up is exact.
-    const float rcp_bf = 1.0f / (float)bf;
-    auto divmod_small = [&](uint32_t x, uint32_t& q, uint32_t& r) {
-        q = (uint32_t)((float)x * rcp_bf);
-        int32_t rr = (int32_t)(x - q * bf);
-        if (rr < 0) { q -= 1; rr += (int32_t)bf; }
-        else if (rr >= (int32_t)bf) { q += 1; rr -= (int32_t)bf; }
-        r = (uint32_t)rr;
-    };
-    uint32_t dq, ph0;
-    divmod_small(phb + 8u * threadIdx.x, dq, ph0);
-    uint32_t S0 = Sb + dq;
-    uint32_t step_q, step_r;                                   // 2048 = step_q * bf + step_r
-    divmod_small(2048u, step_q, step_r);
-
-#pragma unroll 1
-    for (int it = 0; it < kModIters; it++) {
-        const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
-        if (p0 >= len) break;
-        const uint32_t rel = S0 - Sb;                            // three consecutive bits of the bitmap
-        const unsigned long long w0 = kinds[rel >> 6], w1 = kinds[(rel >> 6) + 1u];
-        const uint32_t sh = rel & 63u;
-        const uint32_t kb = (uint32_t)(w0 >> sh) | (sh > 61u ? (uint32_t)(w1 << (64u - sh)) : 0u);
-        const bool k0 = kb & 1u, k1 = kb & 2u, k2 = kb & 4u;
-        // tone of the frame at offset dj from p0 (branch-free)
-        auto frame = [&](uint32_t dj) -> int16_t {
-            const uint32_t phj = ph0 + dj;                      // < bf + 7 < 3*bf
-            const uint32_t w = (uint32_t)(phj >= bf) + (uint32_t)(phj >= 2u * bf);
-            const uint32_t ph = phj - w * bf;
-            const bool mark = w == 0 ? k0 : (w == 1 ? k1 : k2);
-            const uint32_t ph4 = 4u * ph;
-            const bool hi_mark = (ph4 < bf) | ((ph4 >= 2u * bf) & (ph4 < 3u * bf));   // ref:80-85
-            const bool hi_space = 2u * ph < bf;                                          // ref:68-77
-            const int16_t tone = (mark ? hi_mark : hi_space) ? (int16_t)32767 : (int16_t)-32768;
-            return (p0 + dj) < lim ? tone : (int16_t)0;
+        const bool tail = base + kModChunk + 8u > lim;          // the tones end inside this block
+        auto run = [&](auto quirk, auto smallq) {
+            if (tail) tone_block<ITERS, decltype(quirk)::value, decltype(smallq)::value, true>(dst0, base, len, phb, q, qbits, lim);
+            else tone_block<ITERS, decltype(quirk)::value, decltype(smallq)::value, false>(dst0, base, len, phb, q, qbits, lim);
         };
-        pack8 v;
-        if (a.wav_quirk) {        // block-uniform: out[2i] = out[2i+1] = frames[2i] (ref:239-244)
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j += 2) v.v[j] = v.v[j + 1] = frame(j);
+        if (a.wav_quirk) {
+            if (q >= 8u) run(std::true_type{}, std::false_type{});
+            else run(std::true_type{}, std::true_type{});
         } else {
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) v.v[j] = frame(j);
+            if (q >= 8u) run(std::false_type{}, std::false_type{});
+            else run(std::false_type{}, std::true_type{});
         }
-        int16_t* dst = dst0 + p0;
-        if (p0 + 8u <= len) {
-            store_pack8(dst, v);
-        } else {
-#pragma unroll
-            for (uint32_t j = 0; j < 8u; j++)
-                if (p0 + j < len) dst[j] = v.v[j];
-        }
-        // next store of this thread is 2048 samples further
-        S0 += step_q;
-        ph0 += step_r;
-        if (ph0 >= bf) { ph0 -= bf; S0 += 1u; }
     }
 }
 
@@ -307,14 +259,19 @@ __global__ __launch_bounds__(256) void noise_kernel(NoiseArgs a) {
     }
 }
 
-hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream) {
+template <int ITERS>
+hipError_t launch_modulate_t(ModulateArgs a, int32_t max_len, hipStream_t stream) {
     if (a.n_streams <= 0 || max_len <= 0) return hipSuccess;
-    const int per_block = kModChunk;
+    const int per_block = mod_chunk(ITERS);
     a.chunks = (max_len + per_block - 1) / per_block;
     const int64_t blocks = (int64_t)a.chunks * a.n_streams;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(modulate_kernel, dim3((uint32_t)blocks), dim3(kModThreads), 0, stream, a);
+    hipLaunchKernelGGL(modulate_kernel_t<ITERS>, dim3((uint32_t)blocks), dim3(kModThreads), 0, stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream) {
+    return launch_modulate_t<kModIters>(a, max_len, stream);
 }
 
 hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream) {

@@ -128,6 +128,9 @@ int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
  * (truncated, or zero padded after the 4800-sample tail).
  *
  *  payload      uint8 [n, payload_stride]; payload_len [n] bytes used per row
+ *  bit_frames   [n] 48000 / baud; a positive multiple of 4 (every baud rate the reference's
+ *               Waveforms accept, :69-70/:81-82, gives one); any other value yields an
+ *               all-zero stream (device arrays are not validated on the host)
  *  ts_cycles    [n] int(baud * training_time / 2)   (:438)
  *  max_stream_len  host-side upper bound of stream_len[] (sizes the grid)
  */

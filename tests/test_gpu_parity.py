@@ -290,6 +290,18 @@ def test_modulator_every_quarter_width(torch_cuda, wav_quirk):
         bad = np.nonzero(got[sl] != want[sl])[0]
         assert bad.size == 0, (int(bf[i]), int(ln[i]), int(ts[i]), int(plen[i]), bad[:6])
     assert (got[~covered] == 12345).all()                        # nothing written outside the streams
+    # bit_frames outside the domain (not a positive multiple of 4): documented all-zero stream
+    bad_bf = np.array([0, 30, -8, 41], np.int32)
+    o2 = (np.arange(4, dtype=np.int64) * 20000) + 1
+    l2 = np.full(4, 19990, np.int32)
+    s2 = torch.full((80010,), 77, dtype=torch.int16, device=dev)
+    batch.modulate_batch(t(payload[:4].copy()), t(plen[:4].copy()), t(bad_bf), t(ts[:4].copy()), t(o2),
+                         t(l2), 19990, s2, wav_quirk)
+    torch.cuda.synchronize()
+    g2 = s2.cpu().numpy()
+    for i in range(4):
+        assert (g2[o2[i]: o2[i] + l2[i]] == 0).all()
+    assert (g2[:1] == 77).all() and (g2[o2[3] + l2[3]:] == 77).all()
 
 
 @pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])

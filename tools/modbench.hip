@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../afskmodem_amd/csrc/afsk_kernels.h"
+#include "../afskmodem_amd/csrc/afsk_synth.hip"   // the kernels as templates (diagnostic build)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -79,8 +79,15 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(d_payload, payload.data(), payload.size(), hipMemcpyHostToDevice));
         for (int quirk : {1, 0}) {
             afsk::ModulateArgs m{d_payload, plen_v, d_pl, d_bf, d_ts, d_off, d_len, n, quirk, d_x, 0};
-            char nm[64]; snprintf(nm, 64, "modulate %d baud quirk=%d", baud, quirk);
-            rep(nm, time_us([&] { CK(afsk::launch_modulate(m, L, 0)); }));
+            char nm[64];
+            snprintf(nm, 64, "modulate %d baud quirk=%d iters=2", baud, quirk);
+            rep(nm, time_us([&] { CK(afsk::launch_modulate_t<2>(m, L, 0)); }));
+            snprintf(nm, 64, "modulate %d baud quirk=%d iters=4", baud, quirk);
+            rep(nm, time_us([&] { CK(afsk::launch_modulate_t<4>(m, L, 0)); }));
+            snprintf(nm, 64, "modulate %d baud quirk=%d iters=8", baud, quirk);
+            rep(nm, time_us([&] { CK(afsk::launch_modulate_t<8>(m, L, 0)); }));
+            snprintf(nm, 64, "modulate %d baud quirk=%d iters=12", baud, quirk);
+            rep(nm, time_us([&] { CK(afsk::launch_modulate_t<12>(m, L, 0)); }));
         }
     }
     return 0;
