@@ -13,11 +13,12 @@ for w in config3 config4 config5; do
 done
 if [ "${1:-}" = "prof" ]; then
   for w in config2 config3; do
-    steps=50; [ $w = config3 ] && steps=6
+    steps=200; [ $w = config3 ] && steps=20
     rm -rf gpurun_out/prof_trace_$w gpurun_out/prof_pmc1_$w gpurun_out/prof_pmc2_$w
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_trace_$w -- python3 /root/repo/bench.py --workload $w --steps $steps --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 )
-    ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/gpurun_out/prof_pmc1_$w -- python3 /root/repo/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
-    ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /root/repo/gpurun_out/prof_pmc2_$w -- python3 /root/repo/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
-    python tools/summarize_prof.py gpurun_out $w 2>&1 | tail -40
+    ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/gpurun_out/prof_pmc1_$w -- python3 /root/repo/bench.py --workload $w --steps 6 --warmup 2 --preroll-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
+    ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /root/repo/gpurun_out/prof_pmc2_$w -- python3 /root/repo/bench.py --workload $w --steps 6 --warmup 2 --preroll-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
+    python tools/summarize_prof.py gpurun_out $w $steps 2>&1 | tail -40
+    python tools/trace_timeline.py gpurun_out/prof_trace_$w 2>&1 | tee gpurun_out/timeline_$w.txt
   done
 fi

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (kernel trace stats + FETCH_SIZE / WRITE_SIZE PMC passes)
 into a small JSON summary (gpurun_out/prof_summary_<workload>.json) that is then committed
-under profiles/.  Usage: summarize_prof.py <gpurun_out> <workload>"""
+under profiles/.  Usage: summarize_prof.py <gpurun_out> <workload> [timed_steps]
+With timed_steps, "demod_kernel_timed_region" covers the last timed_steps launches of the trace
+(bench.py's timed region; the launches before it are its clock pre-roll and warm-up)."""
 import csv
 import glob
 import json
@@ -10,6 +12,7 @@ import sys
 
 base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
+timed_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 out = {"workload": wl}
 
 
@@ -22,6 +25,12 @@ for f in find("prof_trace", "*kernel_stats.csv"):
     out["kernel_stats_file"] = f
 for f in find("prof_trace", "*kernel_trace.csv"):
     rows = [r for r in csv.DictReader(open(f)) if "demod_kernel" in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if timed_steps and len(rows) >= timed_steps:
+        t = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-timed_steps:])
+        out["demod_kernel_timed_region"] = {"launches": len(t), "avg_ns": sum(t) / len(t),
+                                            "median_ns": t[len(t) // 2], "min_ns": t[0],
+                                            "max_ns": t[-1]}
     d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
     if d:
         out["demod_kernel_trace"] = {"launches": len(d), "avg_ns": sum(d) / len(d),
