@@ -54,26 +54,48 @@ class HostDemodResult:
 
 
 def demod_host_arrays(arrays, bit_frames, amp_end_threshold: int = 14000) -> HostDemodResult:
-    """Demodulate a list of host int16 arrays (ragged) through ``afsk_demod_batch_host``."""
+    """Demodulate a list of host int16 arrays (ragged) through ``afsk_demod_streams_host``:
+    the library gathers the arrays through pinned staging windows itself, so there is no
+    concatenation pass on the Python side."""
     n = len(arrays)
-    lens = np.array([len(a) for a in arrays], dtype=np.int32)
+    keep = [np.ascontiguousarray(a, dtype=np.int16).reshape(-1) for a in arrays]
+    lens = np.array([a.size for a in keep], dtype=np.int32)
     bf = np.broadcast_to(np.asarray(bit_frames, dtype=np.int32), (n,)).copy()
     if n:
         validate_bit_frames(bf)
-    offs = np.zeros(n, dtype=np.int64)
-    if n > 1:
-        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
-    flat = (np.concatenate([np.ascontiguousarray(a, dtype=np.int16) for a in arrays])
-            if n else np.zeros(0, np.int16))
-    if flat.size == 0:
-        flat = np.zeros(1, np.int16)
-        total = 0
-    else:
-        total = flat.size
     stride = out_stride_for(int(lens.max()) if n else 0, int(bf.min()) if n else 4)
     res = HostDemodResult(np.zeros((n, stride), np.uint8), *(np.zeros(n, np.int32) for _ in range(5)))
     if n == 0:
         return res
+    if n == 1:                      # a single array is already "one flat buffer"
+        return demod_host_flat(keep[0], [0], lens, bf, amp_end_threshold, stride)
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in keep])
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+    _native.check(_native.lib().afsk_demod_streams_host(
+        ptrs, p(lens, C.c_int32), p(bf, C.c_int32), int(amp_end_threshold), n,
+        p(res.bytes, C.c_uint8), stride, p(res.nbytes, C.c_int32), p(res.nbits, C.c_int32),
+        p(res.clock_idx, C.c_int32), p(res.term_frame, C.c_int32), p(res.status, C.c_int32)))
+    return res
+
+
+def demod_host_flat(flat, stream_offset, stream_len, bit_frames,
+                    amp_end_threshold: int = 14000, out_stride: int | None = None) -> HostDemodResult:
+    """``afsk_demod_batch_host``: streams given as offset/length pairs into ONE host buffer."""
+    flat = np.ascontiguousarray(flat, dtype=np.int16).reshape(-1)
+    offs = np.ascontiguousarray(stream_offset, dtype=np.int64)
+    lens = np.ascontiguousarray(stream_len, dtype=np.int32)
+    n = offs.size
+    bf = np.broadcast_to(np.asarray(bit_frames, dtype=np.int32), (n,)).copy()
+    if n:
+        validate_bit_frames(bf)
+    stride = out_stride if out_stride is not None else out_stride_for(
+        int(lens.max()) if n else 0, int(bf.min()) if n else 4)
+    res = HostDemodResult(np.zeros((n, stride), np.uint8), *(np.zeros(n, np.int32) for _ in range(5)))
+    if n == 0:
+        return res
+    total = flat.size
+    if total == 0:
+        flat = np.zeros(1, np.int16)
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
     _native.check(_native.lib().afsk_demod_batch_host(
         p(flat, C.c_int16), total, p(offs, C.c_int64), p(lens, C.c_int32), p(bf, C.c_int32),

@@ -3,8 +3,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/afsk_amd.h"
@@ -31,6 +35,107 @@ int require_device() {
         return fail(AFSK_E_NO_DEVICE, "no HIP device visible: libafsk_amd has no CPU fallback");
     }
     return AFSK_OK;
+}
+
+// Device scratch of the host-buffer entry, kept between calls: hipMalloc of a few hundred MB
+// costs tens of ms (75 ms for 393 MB measured, tools/h2d_probe), far more than the transfer.
+// One cached allocation per process, grown on demand; a concurrent caller that finds it busy
+// falls back to a private hipMalloc/hipFree.  afsk_host_scratch_release() frees it.
+constexpr size_t kStageBytes = (size_t)32 << 20;   // pinned staging window of the gather entry
+
+struct ScratchCache {
+    std::mutex mu;
+    char* ptr = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    char* stage[2] = {nullptr, nullptr};            // pinned host windows (afsk_demod_streams_host)
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+};
+ScratchCache g_scratch;
+
+class ScratchLease {
+public:
+    ~ScratchLease() {
+        if (private_ptr_) (void)hipFree(private_ptr_);
+        if (locked_) g_scratch.mu.unlock();
+    }
+    // block = wait for the shared cache instead of falling back to a private allocation
+    hipError_t acquire(size_t bytes, char** out, bool block = false) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (block) g_scratch.mu.lock();
+        if (block || g_scratch.mu.try_lock()) {
+            locked_ = true;
+            if (g_scratch.cap < bytes || g_scratch.device != dev) {
+                if (g_scratch.ptr) (void)hipFree(g_scratch.ptr);
+                g_scratch.ptr = nullptr;
+                g_scratch.cap = 0;
+                const size_t want = (bytes + (bytes >> 3) + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+                e = hipMalloc((void**)&g_scratch.ptr, want);
+                if (e != hipSuccess) { g_scratch.ptr = nullptr; return e; }
+                g_scratch.cap = want;
+                g_scratch.device = dev;
+            }
+            *out = g_scratch.ptr;
+            return hipSuccess;
+        }
+        e = hipMalloc((void**)&private_ptr_, bytes);
+        if (e != hipSuccess) { private_ptr_ = nullptr; return e; }
+        *out = private_ptr_;
+        return hipSuccess;
+    }
+    // the two pinned staging windows (only with a blocking lease, which owns the cache)
+    hipError_t staging(char** s0, char** s1, hipEvent_t* e0, hipEvent_t* e1) {
+        for (int k = 0; k < 2; k++) {
+            if (!g_scratch.stage[k]) {
+                hipError_t e = hipHostMalloc((void**)&g_scratch.stage[k], kStageBytes, hipHostMallocDefault);
+                if (e != hipSuccess) { g_scratch.stage[k] = nullptr; return e; }
+            }
+            if (!g_scratch.stage_free[k]) {
+                hipError_t e = hipEventCreateWithFlags(&g_scratch.stage_free[k], hipEventDisableTiming);
+                if (e != hipSuccess) { g_scratch.stage_free[k] = nullptr; return e; }
+            }
+        }
+        *s0 = g_scratch.stage[0]; *s1 = g_scratch.stage[1];
+        *e0 = g_scratch.stage_free[0]; *e1 = g_scratch.stage_free[1];
+        return hipSuccess;
+    }
+private:
+    bool locked_ = false;
+    char* private_ptr_ = nullptr;
+};
+
+struct CopyJob { char* dst; const char* src; size_t bytes; };
+
+// memcpy a list of pieces, split over a few threads when it is worth it (one core moves
+// ~30 GB/s into pinned memory, the PCIe link takes ~56 GB/s: tools/h2d_probe)
+void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
+    static const unsigned max_threads = [] {
+        const char* e = std::getenv("AFSK_COPY_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(8u, std::max(1u, hw / 2));
+    }();
+    unsigned nt = total >= ((size_t)4 << 20) ? max_threads : 1u;
+    if (nt <= 1) {
+        for (const CopyJob& j : jobs) std::memcpy(j.dst, j.src, j.bytes);
+        return;
+    }
+    const size_t share = (total + nt - 1) / nt;
+    std::vector<std::thread> th;
+    size_t ji = 0, joff = 0;                       // cursor: job index, byte offset inside it
+    for (unsigned t = 0; t < nt && ji < jobs.size(); t++) {
+        std::vector<CopyJob> mine;
+        size_t left = share;
+        while (left > 0 && ji < jobs.size()) {
+            const size_t take = std::min(left, jobs[ji].bytes - joff);
+            mine.push_back({jobs[ji].dst + joff, jobs[ji].src + joff, take});
+            left -= take; joff += take;
+            if (joff == jobs[ji].bytes) { ji++; joff = 0; }
+        }
+        th.emplace_back([mine = std::move(mine)] { for (const CopyJob& j : mine) std::memcpy(j.dst, j.src, j.bytes); });
+    }
+    for (auto& x : th) x.join();
 }
 
 #define AFSK_HIP(call, what)                             \
@@ -133,43 +238,162 @@ int afsk_demod_batch_host(const int16_t* samples, int64_t total_samples,
     int rc = AFSK_OK;
     const size_t n = (size_t)n_streams;
     const size_t sample_bytes = (size_t)(total_samples > 0 ? total_samples : 1) * 2;
-    const size_t bytes_out = n * (size_t)(out_stride > 0 ? out_stride : 1);
-    char* d_all = nullptr;
-    // one allocation: samples | offsets | len | bf | 5 x int32 outputs | bytes
-    size_t o_samples = 0;
-    size_t o_off = (sample_bytes + 15) & ~(size_t)15;
-    size_t o_len = o_off + n * 8;
-    size_t o_bf = o_len + n * 4;
-    size_t o_i32 = o_bf + n * 4;
-    size_t o_bytes = o_i32 + 5 * n * 4;
-    size_t total = o_bytes + bytes_out;
+    const size_t bytes_out = n * (size_t)out_stride;
+    // device layout: samples | meta = offsets, len, bf | out = 5 x int32 [n], bytes [n, stride]
+    const size_t o_meta = (sample_bytes + 255) & ~(size_t)255;
+    const size_t meta_bytes = n * 16;
+    const size_t o_out = o_meta + meta_bytes;
+    const size_t out_bytes_total = n * 20 + bytes_out;
+    const size_t total = o_out + out_bytes_total;
     hipStream_t stream = nullptr;
-    AFSK_HIP(hipMalloc((void**)&d_all, total), "hipMalloc");
-    if (total_samples > 0)
-        AFSK_HIP(hipMemcpyAsync(d_all + o_samples, samples, (size_t)total_samples * 2,
-                                hipMemcpyHostToDevice, stream), "H2D samples");
-    AFSK_HIP(hipMemcpyAsync(d_all + o_off, stream_offset, n * 8, hipMemcpyHostToDevice, stream), "H2D offsets");
-    AFSK_HIP(hipMemcpyAsync(d_all + o_len, stream_len, n * 4, hipMemcpyHostToDevice, stream), "H2D lengths");
-    AFSK_HIP(hipMemcpyAsync(d_all + o_bf, bit_frames, n * 4, hipMemcpyHostToDevice, stream), "H2D bit_frames");
+    ScratchLease lease;
+    char* d_all = nullptr;
+    // host staging: one H2D for the three index arrays, one D2H for all six outputs
+    std::vector<char> h_meta(meta_bytes), h_out(out_bytes_total);
+    std::memcpy(h_meta.data(), stream_offset, n * 8);
+    std::memcpy(h_meta.data() + n * 8, stream_len, n * 4);
+    std::memcpy(h_meta.data() + n * 12, bit_frames, n * 4);
     {
-        int32_t* i32 = (int32_t*)(d_all + o_i32);
-        rc = afsk_demod_batch((const int16_t*)(d_all + o_samples), (const int64_t*)(d_all + o_off),
-                              (const int32_t*)(d_all + o_len), (const int32_t*)(d_all + o_bf),
-                              amp_end_threshold, n_streams, (uint8_t*)(d_all + o_bytes), out_stride,
-                              i32, i32 + n, i32 + 2 * n, i32 + 3 * n, i32 + 4 * n, stream);
-        if (rc != AFSK_OK) goto done;
-        AFSK_HIP(hipMemcpyAsync(out_nbytes, i32, n * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        AFSK_HIP(hipMemcpyAsync(out_nbits, i32 + n, n * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        AFSK_HIP(hipMemcpyAsync(out_clock_idx, i32 + 2 * n, n * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        AFSK_HIP(hipMemcpyAsync(out_term_frame, i32 + 3 * n, n * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        AFSK_HIP(hipMemcpyAsync(out_status, i32 + 4 * n, n * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        if (out_stride > 0)
-            AFSK_HIP(hipMemcpyAsync(out_bytes, d_all + o_bytes, n * (size_t)out_stride,
-                                    hipMemcpyDeviceToHost, stream), "D2H bytes");
+        hipError_t e = lease.acquire(total, &d_all);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-entry scratch)");
     }
+    if (total_samples > 0)
+        AFSK_HIP(hipMemcpyAsync(d_all, samples, (size_t)total_samples * 2, hipMemcpyHostToDevice, stream),
+                 "H2D samples");
+    AFSK_HIP(hipMemcpyAsync(d_all + o_meta, h_meta.data(), meta_bytes, hipMemcpyHostToDevice, stream),
+             "H2D stream index");
+    {
+        int32_t* i32 = (int32_t*)(d_all + o_out);
+        rc = afsk_demod_batch((const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+                              (const int32_t*)(d_all + o_meta + n * 8),
+                              (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
+                              (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
+                              i32 + 3 * n, i32 + 4 * n, stream);
+        if (rc != AFSK_OK) goto done;
+    }
+    AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
+             "D2H results");
     AFSK_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    std::memcpy(out_nbytes, h_out.data(), n * 4);
+    std::memcpy(out_nbits, h_out.data() + n * 4, n * 4);
+    std::memcpy(out_clock_idx, h_out.data() + n * 8, n * 4);
+    std::memcpy(out_term_frame, h_out.data() + n * 12, n * 4);
+    std::memcpy(out_status, h_out.data() + n * 16, n * 4);
+    if (bytes_out > 0) std::memcpy(out_bytes, h_out.data() + n * 20, bytes_out);
 done:
-    if (d_all) (void)hipFree(d_all);
+    return rc;   // the lease returns (or frees) the device scratch
+}
+
+int afsk_host_scratch_release(void) {
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    if (g_scratch.ptr) {
+        hipError_t e = hipFree(g_scratch.ptr);
+        g_scratch.ptr = nullptr;
+        g_scratch.cap = 0;
+        if (e != hipSuccess) return hip_fail(e, "hipFree (host-entry scratch)");
+    }
+    for (int k = 0; k < 2; k++) {
+        if (g_scratch.stage[k]) { (void)hipHostFree(g_scratch.stage[k]); g_scratch.stage[k] = nullptr; }
+        if (g_scratch.stage_free[k]) { (void)hipEventDestroy(g_scratch.stage_free[k]); g_scratch.stage_free[k] = nullptr; }
+    }
+    return AFSK_OK;
+}
+
+int afsk_demod_streams_host(const int16_t* const* streams, const int32_t* stream_len,
+                            const int32_t* bit_frames, int32_t amp_end_threshold,
+                            int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
+                            int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                            int32_t* out_term_frame, int32_t* out_status) {
+    if (n_streams < 0 || out_stride < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (n_streams == 0) return AFSK_OK;
+    if (!streams || !stream_len || !bit_frames || !out_nbytes || !out_nbits || !out_clock_idx ||
+        !out_term_frame || !out_status || (!out_bytes && out_stride > 0))
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    const size_t n = (size_t)n_streams;
+    // device layout: every stream starts on a 16-byte boundary
+    std::vector<char> h_meta(n * 16);
+    int64_t* h_off = (int64_t*)h_meta.data();
+    int64_t total_samples = 0;
+    for (size_t s = 0; s < n; s++) {
+        const int bf = bit_frames[s];
+        if (bf < 4 || (bf & 3) || 2 * bf >= AFSK_SYNC_WINDOW)
+            return fail(AFSK_E_INVALID_BAUD, "bit_frames must be a multiple of 4 with 2*bf < 4096");
+        if (stream_len[s] < 0 || stream_len[s] >= (1 << 30) || (stream_len[s] > 0 && !streams[s]))
+            return fail(AFSK_E_INVALID_ARG, "bad stream length or null stream pointer");
+        h_off[s] = total_samples;
+        total_samples += ((int64_t)stream_len[s] + 7) & ~(int64_t)7;
+    }
+    std::memcpy(h_meta.data() + n * 8, stream_len, n * 4);
+    std::memcpy(h_meta.data() + n * 12, bit_frames, n * 4);
+    if (int rc0 = require_device()) return rc0;
+
+    int rc = AFSK_OK;
+    const size_t sample_bytes = (size_t)(total_samples > 0 ? total_samples : 1) * 2;
+    const size_t bytes_out = n * (size_t)out_stride;
+    const size_t o_meta = (sample_bytes + 255) & ~(size_t)255;
+    const size_t o_out = o_meta + n * 16;
+    const size_t out_bytes_total = n * 20 + bytes_out;
+    hipStream_t stream = nullptr;
+    ScratchLease lease;
+    char* d_all = nullptr;
+    char* stage[2];
+    hipEvent_t stage_free[2];
+    std::vector<char> h_out(out_bytes_total);
+    {
+        hipError_t e = lease.acquire(o_out + out_bytes_total, &d_all, /*block=*/true);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-entry scratch)");
+        e = lease.staging(&stage[0], &stage[1], &stage_free[0], &stage_free[1]);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (staging)");
+    }
+    {
+        // windows of the device sample range; pieces of streams are packed into a pinned window
+        // by the copy threads while the previous window is on the wire
+        const size_t all = (size_t)total_samples * 2;
+        // small batches use smaller windows so that packing and DMA still overlap
+        const size_t win = std::min(kStageBytes, std::max((size_t)1 << 20, ((all / 4) + 65535) & ~(size_t)65535));
+        size_t s_cur = 0;                                  // first stream that may reach into the window
+        std::vector<CopyJob> jobs;
+        for (size_t w0 = 0, k = 0; w0 < all; w0 += win, k++) {
+            const size_t w1 = std::min(all, w0 + win);
+            char* st = stage[k & 1];
+            if (k >= 2) AFSK_HIP(hipEventSynchronize(stage_free[k & 1]), "hipEventSynchronize");
+            jobs.clear();
+            size_t moved = 0;
+            for (size_t s = s_cur; s < n; s++) {
+                const size_t b0 = (size_t)h_off[s] * 2, b1 = b0 + (size_t)stream_len[s] * 2;
+                if (b0 >= w1) break;
+                if (b1 <= w0) { s_cur = s + 1; continue; }
+                const size_t lo = std::max(b0, w0), hi = std::min(b1, w1);
+                jobs.push_back({st + (lo - w0), (const char*)streams[s] + (lo - b0), hi - lo});
+                moved += hi - lo;
+            }
+            parallel_copy(jobs, moved);
+            AFSK_HIP(hipMemcpyAsync(d_all + w0, st, w1 - w0, hipMemcpyHostToDevice, stream), "H2D samples");
+            AFSK_HIP(hipEventRecord(stage_free[k & 1], stream), "hipEventRecord");
+        }
+    }
+    AFSK_HIP(hipMemcpyAsync(d_all + o_meta, h_meta.data(), n * 16, hipMemcpyHostToDevice, stream),
+             "H2D stream index");
+    {
+        int32_t* i32 = (int32_t*)(d_all + o_out);
+        rc = afsk_demod_batch((const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+                              (const int32_t*)(d_all + o_meta + n * 8),
+                              (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
+                              (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
+                              i32 + 3 * n, i32 + 4 * n, stream);
+        if (rc != AFSK_OK) goto done;
+    }
+    AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
+             "D2H results");
+    AFSK_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    std::memcpy(out_nbytes, h_out.data(), n * 4);
+    std::memcpy(out_nbits, h_out.data() + n * 4, n * 4);
+    std::memcpy(out_clock_idx, h_out.data() + n * 8, n * 4);
+    std::memcpy(out_term_frame, h_out.data() + n * 12, n * 4);
+    std::memcpy(out_status, h_out.data() + n * 16, n * 4);
+    if (bytes_out > 0) std::memcpy(out_bytes, h_out.data() + n * 20, bytes_out);
+done:
+    if (rc != AFSK_OK) (void)hipStreamSynchronize(stream);   // nothing may still read the staging windows
     return rc;
 }
 

@@ -122,6 +122,25 @@ int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           int32_t *out_term_frame, int32_t *out_status);
 
 /*
+ * Gather form of the host entry: stream s is the host array streams[s] of stream_len[s]
+ * samples (no concatenated buffer needed -- e.g. one array per .wav file or per
+ * Receiver.load()-style frame list).  The streams are packed through two pinned 32 MiB
+ * windows by a few copy threads while the previous window is on the PCIe link, then
+ * demodulated with one launch.  Calls serialise on the cached staging buffers.
+ */
+int afsk_demod_streams_host(const int16_t *const *streams, const int32_t *stream_len,
+                            const int32_t *bit_frames, int32_t amp_end_threshold,
+                            int32_t n_streams, uint8_t *out_bytes, int32_t out_stride,
+                            int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
+                            int32_t *out_term_frame, int32_t *out_status);
+
+/* The host entries keep their device scratch (samples + results) allocated between
+ * calls (and the gather entry its pinned windows), because hipMalloc of a large buffer costs
+ * far more than the transfer; this frees them.
+ * Safe to call at any time; the next host-entry call allocates again. */
+int afsk_host_scratch_release(void);
+
+/*
  * On-device input synthesis: Transmitter.__getFrames (:452-469) with ECC.encode
  * (:166-175) and, when wav_quirk != 0, SoundOutput.__convertFrames' decimate-by-2
  * + duplicate (:239-244), written to samples[stream_offset[s] .. +stream_len[s])

@@ -75,6 +75,53 @@ def test_golden_cases_host_entry(golden, torch_cuda):
             assert res.status[j] == want, c["tag"]
 
 
+def test_golden_cases_flat_host_entry_and_scratch_reuse(golden, torch_cuda):
+    """afsk_demod_batch_host (one host buffer + offsets, with gaps between the streams) and
+    the gather entry give the same results; the cached device scratch is reused, grown and
+    released between calls without changing them."""
+    cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]
+    xs = [build_input(c) for c in cases]
+    bf = [48000 // c["baud"] for c in cases]
+    want = batch.demod_host_arrays(xs, bf)
+    gaps = [(7 * i) % 5 for i in range(len(xs))]
+    ln = np.array([len(x) for x in xs], np.int32)
+    off = np.cumsum([3] + [int(l) + g for l, g in zip(ln[:-1], gaps[:-1])]).astype(np.int64)
+    flat = np.full(int(off[-1] + ln[-1] + 4), 999, np.int16)
+    for o, x in zip(off, xs):
+        flat[o: o + len(x)] = x
+    for rep in range(3):
+        if rep == 2:
+            _native.check(_native.lib().afsk_host_scratch_release())
+        sub = slice(0, len(xs) if rep != 1 else 5)          # smaller batch reuses the big scratch
+        got = batch.demod_host_flat(flat, off[sub], ln[sub], bf[sub], out_stride=want.bytes.shape[1])
+        for f in FIELDS:
+            assert np.array_equal(getattr(got, f), getattr(want, f)[sub]), (rep, f)
+        assert got.payloads() == want.payloads()[sub]
+    _native.check(_native.lib().afsk_host_scratch_release())
+    _native.check(_native.lib().afsk_host_scratch_release())      # idempotent
+    assert batch.demod_host_arrays(xs[:3], bf[:3]).payloads() == want.payloads()[:3]
+
+
+def test_gather_host_entry_large_batch_crosses_staging_windows(torch_cuda):
+    """afsk_demod_streams_host with > 32 MiB of samples (several pinned windows, streams
+    straddling window boundaries, an over-long stream, empty streams) equals the device path."""
+    torch = torch_cuda
+    b = synth_batch(torch, 900, (1200, 300, 2400), seed=5, snr_db=None)
+    host = b["samples"].cpu().numpy().reshape(900, -1)
+    arrays = [host[i, : 48000 - (i % 13) * 3] for i in range(900)]   # ragged, odd lengths
+    arrays[17] = np.zeros(0, np.int16)
+    arrays[500] = np.concatenate([host[500], host[501], host[502]])  # 144000 samples
+    bf = b["h_bf"].copy()
+    got = batch.demod_host_arrays(arrays, bf)
+    ln = np.array([a.size for a in arrays], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    want = device_demod(torch, np.concatenate(arrays), off, ln, bf, stride=got.bytes.shape[1])
+    for f in FIELDS:
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    assert got.payloads() == want.payloads()
+    assert got.status[17] == _native.ST_TOO_SHORT and int((got.status == 0).sum()) >= 890
+
+
 def test_golden_cases_device_entry(golden, torch_cuda):
     """Same cases through afsk_demod_batch on device tensors, one mixed-baud launch."""
     cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]
