@@ -54,8 +54,9 @@ def main() -> None:
                          "GPU clocks have settled (the first ~20 ms under load run 4-6 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=0)
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="N > 1: all-gather the decoded records of G steps with one collective")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: all-gather the decoded records of G steps with one collective; "
+                         "0 = as many steps as take about 4 ms (at most 64)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
     args = ap.parse_args()
@@ -112,7 +113,14 @@ def main() -> None:
     # ("fewer, larger collectives"): when a group of G steps has been launched, its G flat
     # buffers -- contiguous in memory -- are all-gathered on a side stream while the other
     # group is being filled.
-    G = max(1, args.gather_every)
+    # Each collective costs the compute stream ~40 us (cross-stream events around it; measured
+    # with --force-gather: +37 us per step at G = 1, +1 us per step at G = 64), so a group
+    # should cover a few ms of kernels: 64 steps of config #2, 3-4 steps of the 6.29 GB configs.
+    if args.gather_every > 0:
+        G = args.gather_every
+    else:
+        est_step_s = 2.0 * n_local * STREAM_LEN / 6.0e12
+        G = max(1, min(64, int(4e-3 / est_step_s)))
     _, flat_sz = batch.flat_layout(n_local, stride)
     group_flat = [torch.zeros(G * flat_sz, dtype=torch.uint8, device=dev) for _ in range(2)]
     outs = [[batch.views_of_flat(gf[k * flat_sz: (k + 1) * flat_sz], n_local, stride)
@@ -142,12 +150,22 @@ def main() -> None:
     gathers = 0
     last_slot = (0, 0)
 
+    gather_timing = []        # (start, end) events of the collectives inside the timed region
+    timing_on = False
+
     def gather_group(grp: int) -> None:
         nonlocal gathers
         ready_ev[grp].record(cur)
         comm.wait_event(ready_ev[grp])
         with torch.cuda.stream(comm):
+            pair = None
+            if timing_on and len(gather_timing) < 256:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(comm)
             dist.all_gather_into_tensor(gath_bufs[grp], group_flat[grp])
+            if pair is not None:
+                pair[1].record(comm)
+                gather_timing.append(pair)
             done_ev[grp].record(comm)
         gathers += 1
 
@@ -193,6 +211,7 @@ def main() -> None:
     finish(args.warmup)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timing_on = True
     t0 = time.perf_counter()
     ev0.record(cur)
     for i in range(args.steps):
@@ -319,6 +338,12 @@ def main() -> None:
         mine = gath_bufs[grp][rank * G * flat_sz + k * flat_sz: rank * G * flat_sz + (k + 1) * flat_sz]
         out["gather_check"] = bool(torch.equal(mine, group_flat[grp][k * flat_sz: (k + 1) * flat_sz]))
         out["gathers_in_timed_region"] = (args.steps + G - 1) // G
+        if gather_timing:
+            # duration of the RCCL all-gather itself (comm stream, overlapped with the next
+            # group's kernels), reported separately as SURVEY 8(d) config 5 asks
+            gms = sorted(a.elapsed_time(b) for a, b in gather_timing)
+            out["gather_ms"] = {"median": round(gms[len(gms) // 2], 4), "max": round(gms[-1], 4),
+                                "bytes_per_rank": int(G * flat_sz), "measured": len(gms)}
         out["config"]["gather_every_steps"] = G
     if rank == 0:
         print(json.dumps(out), flush=True)
