@@ -1,5 +1,5 @@
 // afsk_demod_fast.h -- stream-aligned single-pass path for the common baud rates
-// (bit_frames 20 / 40 / 160 = 2400 / 1200 / 300 baud).  Included by afsk_demod_impl.h.
+// (bit_frames 20 / 40 / 80 / 160 = 2400 / 1200 / 600 / 300 baud).  Included by afsk_demod_impl.h.
 //
 // Every sample is fetched from HBM exactly once: the wave starts a 16 KiB LDS-DMA
 // ring at sample 0 the moment it starts, BEFORE the clock index is known, so the
@@ -470,30 +470,42 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
                 return __ballot(va & 1);
             });
         }
-    } else {                                  // BF == 160: four lanes per symbol, one quarter each
-        static_assert(BF == 160, "fast path supports bit_frames 20, 40, 160");
-        const int quarter = lane & 3;
-        const uint32_t h = hi_sad<0, 20>(x);
-        const uint32_t l = FULL * Q - h;                          // SAD of this quarter vs a lo template
-        uint32_t mark = (quarter & 1) ? l : h;
-        uint32_t space = quarter < 2 ? h : l;
+    } else {                                  // BF = 80 / 160: two / four lanes per symbol
+        static_assert(BF == 80 || BF == 160, "fast path supports bit_frames 20, 40, 80, 160");
+        constexpr int LPS = BF / 40;                               // lanes per symbol
+        constexpr int QPL = 4 / LPS;                               // quarters per lane (2 or 1)
+        constexpr int DPQ = 20 / QPL;                              // dwords per quarter
+        constexpr int SPP = 64 / LPS;                              // symbols per pass
+        const int part = lane & (LPS - 1);
+        // quarter qi of the symbol: mark template hi,lo,hi,lo (ref:80-85), space hi,hi,lo,lo (ref:68-77);
+        // the SAD against a lo template is 65535 * Q minus the SAD against the hi template
+        uint32_t mark, space;
+        if constexpr (QPL == 1) {
+            const uint32_t h = hi_sad<0, 20>(x), l = FULL * Q - h;
+            mark = (part & 1) ? l : h;
+            space = part < 2 ? h : l;
+        } else {
+            const uint32_t ha = hi_sad<0, DPQ>(x), hb = hi_sad<DPQ, 20>(x);
+            mark = ha + (FULL * Q - hb);                           // quarters 2*part (even), 2*part+1 (odd)
+            space = part == 0 ? ha + hb : 2u * FULL * Q - ha - hb;
+        }
 #pragma unroll
-        for (int s = 1; s < 4; s <<= 1) {
+        for (int s = 1; s < LPS; s <<= 1) {
             mark += (uint32_t)__shfl_xor((int)mark, s, 64);
             space += (uint32_t)__shfl_xor((int)space, s, 64);
         }
         const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
         const bool bit = md < sd;
-        if (margins && quarter == 0 && k0 + (lane >> 2) < mlim)
-            margins[k0 + (lane >> 2)] = (int32_t)sd - (int32_t)md;
-        const int srcl = (lane * 4) & 63;                          // lane j < 16 <- symbol j
-        const int nv = (K - k0) < 16 ? (K - k0) : 16;
-        const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < 16);
-        rxd_pass<16>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
+        if (margins && part == 0 && k0 + lane / LPS < mlim)
+            margins[k0 + lane / LPS] = (int32_t)sd - (int32_t)md;
+        const int srcl = (lane * LPS) & 63;                        // lane j < SPP <- symbol j
+        const int nv = (K - k0) < SPP ? (K - k0) : SPP;
+        const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < SPP);
+        rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
             uint32_t amp = abs_sum<0, 20>(x);
 #pragma unroll
-            for (int s = 1; s < 4; s <<= 1) amp += (uint32_t)__shfl_xor((int)amp, s, 64);
-            return (uint64_t)__ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < 16);
+            for (int s = 1; s < LPS; s <<= 1) amp += (uint32_t)__shfl_xor((int)amp, s, 64);
+            return (uint64_t)__ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < SPP);
         });
     }
 }
@@ -506,7 +518,7 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
                                             uint32_t amp_thr, RxDeferred& rd,
                                             unsigned long long* words, uint8_t* out_row,
                                             int out_stride, int32_t* margins, int32_t mstride) {
-    constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
+    constexpr int SPR = 2560 / BF;                                // symbols per 5 KiB round
     const int lane = fr.lane;
     const int shift = byte0 & 15;
     for (int r = 0; r < NR; r++) {
@@ -569,7 +581,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   int32_t& n_sym_out,
                                                   unsigned long long* stamps = nullptr,
                                                   int32_t* margins = nullptr, int32_t mstride = 0) {
-    constexpr int SPR = BF == 40 ? 64 : (BF == 20 ? 128 : 16);   // symbols per 5 KiB round
+    constexpr int SPR = 2560 / BF;                                // symbols per 5 KiB round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
@@ -605,7 +617,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
     }
     // phase C state; its bit buffer reuses the LDS behind the ring (phase A's window is done)
-    constexpr int PS = BF == 160 ? 16 : 64;
+    constexpr int PS = SPR < 64 ? SPR : 64;                      // symbols per rxd pass
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
     RxDeferred rd;
     rxd_init(rd);

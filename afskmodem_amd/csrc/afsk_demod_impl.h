@@ -9,8 +9,8 @@
 // of ref:94-98, Hamming(7,4) decode ref:145-163 and MSB-first byte pack ref:393-399.
 //
 // Two implementations share this file's helpers:
-//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for bit_frames 20 / 40 / 160
-//     (2400 / 1200 / 300 baud); every sample is fetched from HBM exactly once.
+//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for bit_frames 20 / 40 / 80 / 160
+//     (2400 / 1200 / 600 / 300 baud); every sample is fetched from HBM exactly once.
 //   * the two-pass path below (recover_clock_index + demod_symbols*): a full 4096-entry prefix
 //     array for phase A, then a clock-index-aligned ring; used for every other valid
 //     bit_frames (demod_symbols_generic) and, with FAST = false, as the round-1 v1 kernel of
@@ -518,6 +518,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
         switch (bf) {
             case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             default:  done = false; break;
         }

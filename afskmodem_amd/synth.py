@@ -13,7 +13,7 @@ SAMPLE_RATE = 48000
 TAIL_SILENCE = 4800
 
 # payload bytes that make an exactly-1-s stream at training_time 0.5
-ONE_SECOND_PAYLOAD = {300: 8, 1200: 34, 2400: 68}
+ONE_SECOND_PAYLOAD = {300: 8, 600: 16, 1200: 34, 2400: 68}
 
 
 def _hash32(x: np.ndarray) -> np.ndarray:

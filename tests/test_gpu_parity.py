@@ -351,7 +351,7 @@ def test_modulator_every_quarter_width(torch_cuda, wav_quirk):
     assert (g2[:1] == 77).all() and (g2[o2[3] + l2[3]:] == 77).all()
 
 
-@pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])
+@pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (512, (600,)), (256, (600, 1200, 300, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])
 def test_clean_batches_vs_oracle(torch_cuda, n, bauds):
     """Config #2 / #3 shapes at test size: every output equals the CPU oracle's, and the
     decoded payload equals what was modulated (round trip)."""
@@ -387,7 +387,7 @@ def test_noise_sweep_vs_oracle(torch_cuda):
     ber_ok = [all(got.payloads()[i][:34] == b["payload"][i, :34].tobytes()
                   for i in range(k * 64, k * 64 + 64)) for k in range(len(snrs))]
     assert ber_ok[0] and ber_ok[4]          # 30 dB and 10 dB decode error-free
-    for baud, bf in ((300, 160), (2400, 20)):
+    for baud, bf in ((300, 160), (2400, 20), (600, 80)):
         bb = synth_batch(torch, 96, (baud,), seed=32 + bf, snr_db=np.repeat([12, 6, 2], 32))
         st = batch.out_stride_for(bb["total"], bf)
         g = batch.demod_batch(bb["samples"], bb["off"], bb["ln"], bf, 14000, out_stride=st).cpu()
@@ -555,16 +555,16 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
 
 def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     """The single-pass kernel re-aligns ring reads by (2*ci) & 15: exercise all 8 shifts, ring
-    wrap-around on long streams, and tiny symbol counts, for 300 / 1200 / 2400 baud."""
+    wrap-around on long streams, and tiny symbol counts, for 300 / 600 / 1200 / 2400 baud."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     pieces, bfs = [], []
-    for baud in (300, 1200, 2400):
+    for baud in (300, 600, 1200, 2400):
         bf = 48000 // baud
         t = afskmodem.Transmitter(baud, 0.1)
         w_short = t.wav_samples(rng.integers(0, 256, 4, dtype=np.uint8).tobytes())
         w_long = afskmodem.Transmitter(baud, 0.3).wav_samples(
-            rng.integers(0, 256, {300: 40, 1200: 160, 2400: 320}[baud], dtype=np.uint8).tobytes())
+            rng.integers(0, 256, {300: 40, 600: 80, 1200: 160, 2400: 320}[baud], dtype=np.uint8).tobytes())
         for lead in list(range(0, 9)) + [15, 16, 17, 511, 517, 1023, 2047, 3000]:
             pieces.append(np.concatenate([rng.integers(-400, 400, lead).astype(np.int16), w_short]))
             bfs.append(bf)

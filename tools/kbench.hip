@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 3 ? atoi(argv[3]) : 15;
     const int reps = argc > 4 ? atoi(argv[4]) : 5;
     const int L = 48000, bfv = 48000 / baud;
-    const int plen_v = baud == 1200 ? 34 : (baud == 300 ? 8 : 68);
+    const int plen_v = baud == 1200 ? 34 : (baud == 300 ? 8 : (baud == 600 ? 16 : 68));
     std::vector<int64_t> off(n); std::vector<int32_t> len(n, L), bf(n, bfv), pl(n, plen_v), ts(n, baud / 4);
     std::vector<uint8_t> payload((size_t)n * plen_v);
     for (size_t i = 0; i < payload.size(); i++) payload[i] = (uint8_t)((i * 2654435761u) >> 13);
