@@ -412,56 +412,88 @@ __device__ __forceinline__ void demod_symbols(const int16_t* xs, int32_t len, in
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
-// Generic fallback: any bf (multiple of 4, 2*bf < 4096), one lane per symbol,
-// sample-by-sample from LDS.  Correctness path for unusual baud rates.
+__device__ __forceinline__ void wait_vmcnt_upto8(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;
+        default: wait_vmcnt<8>(); break;
+    }
+}
+
+// Generic fallback: any bf (multiple of 4, 2*bf < 4096), one lane per symbol.  Correctness
+// path for unusual baud rates: two 8 KiB LDS slots (the DMA of round r+1 overlaps the
+// arithmetic of round r), four samples per step with the packed limiter and v_sad_u16; the
+// mark/space templates of a step are the same for every lane (all symbols of a round are at
+// the same phase), so the quarter bookkeeping stays on the scalar unit.
 __device__ __forceinline__ void demod_symbols_generic(const int16_t* xs, int32_t len, int ci,
                                                       int bf, int32_t amp_end, uint8_t* lds,
                                                       int lane, RxState& st, uint8_t* out_row,
                                                       int out_stride, int32_t& n_sym_out,
                                                       int32_t* margins = nullptr,
                                                       int32_t margin_stride = 0) {
+    constexpr int kSlot = kWaveLds / 2;
     const int q = bf >> 2, h = bf >> 1;
-    const int sym_b = bf * 2;
-    int spr = (kWaveLds - 16) / sym_b;
+    const int sym_b = bf * 2;                          // bytes per symbol, a multiple of 8
+    int spr = kSlot / sym_b;                           // symbols per round: 2 .. 64
     if (spr > 64) spr = 64;
     const int rb = spr * sym_b;
-    const int nch = (rb + 1023) / 1024;
+    const int nch = (rb + 1023) >> 10;                 // 1 KiB DMA instructions per round, <= 8
     const int32_t rel_len = len - ci;
-    const int32_t K = (rel_len - bf + bf - 1) / bf;
+    const int32_t K = (rel_len - bf + bf - 1) / bf;    // symbols with i < len - bf (ref:362,372)
     n_sym_out = K;
     const int32_t NR = (K + spr - 1) / spr;
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + ci), 0, rel_len * 2, 0x00020000);
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)bf;
     const float rcp_bf = 1.0f / (float)bf;
-    for (int r = 0; r < NR; r++) {
+    auto issue_round = [&](int r) {
+        uint8_t* slot = lds + (r & 1) * kSlot;
         for (int c = 0; c < nch; c++) {
-            if (c * 1024 + lane * 16 < rb)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(lds + c * 1024), 16,
+            if (c * 1024 + lane * 16 < rb)             // lane 0 always issues: vmcnt counts nch per round
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(slot + c * 1024), 16,
                                                          lane * 16 + c * 1024, r * rb, 0, 0);
         }
-        wait_vmcnt<0>();
-        const int16_t* src = reinterpret_cast<const int16_t*>(lds + (lane < spr ? lane : 0) * sym_b);
+    };
+    if (NR > 0) issue_round(0);
+    for (int r = 0; r < NR; r++) {
+        if (r + 1 < NR) {
+            issue_round(r + 1);
+            wait_vmcnt_upto8(nch);                     // round r has landed, round r+1 may be in flight
+        } else {
+            wait_vmcnt<0>();
+        }
+        const uint8_t* src = lds + (r & 1) * kSlot + (lane < spr ? lane : 0) * sym_b;
         uint32_t mark = 0, space = 0, amp = 0;
-        for (int j = 0; j < bf; j++) {
-            const int32_t x = src[j];
-            const int32_t a = x > 512 ? 32767 : (x < -512 ? -32768 : 0);       // ref:287-296
-            const int32_t tm = ((j / q) & 1) ? -32768 : 32767;
-            const int32_t ts = j < h ? 32767 : -32768;
-            mark += (uint32_t)(tm > a ? tm - a : a - tm);
-            space += (uint32_t)(ts > a ? ts - a : a - ts);
-            amp += (uint32_t)(x < 0 ? -x : x);
+        int qi = 0, nb = q;                            // quarter of the current phase, next boundary (uniform)
+        for (int it = 0; it < q; it++) {               // 4 samples per step: phases 4*it .. 4*it+3
+            const u32x2 w = *reinterpret_cast<const u32x2*>(src + 8 * it);
+            uint32_t tmh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (4 * it + j == nb) { qi++; nb += q; }
+                tmh[j] = (qi & 1) ? 0x0000u : 0xFFFFu;                         // hi on quarters 0, 2 (ref:80-85)
+            }
+            const uint32_t ts = 4 * it < h ? 0xFFFFFFFFu : 0u;                 // hi on the first half (ref:68-77; h % 2 == 0)
+            const uint32_t l0 = limit_pair_biased(w[0]), l1 = limit_pair_biased(w[1]);   // ref:344
+            mark = __builtin_amdgcn_sad_u16(l0, tmh[0] | (tmh[1] << 16), mark);          // ref:346
+            mark = __builtin_amdgcn_sad_u16(l1, tmh[2] | (tmh[3] << 16), mark);
+            space = __builtin_amdgcn_sad_u16(l0, ts, space);                             // ref:347
+            space = __builtin_amdgcn_sad_u16(l1, (4 * it + 2 < h) ? 0xFFFFFFFFu : 0u, space);
+            amp = __builtin_amdgcn_sad_u16(w[0] ^ kBias, kBias, amp);                    // ref:94-98
+            amp = __builtin_amdgcn_sad_u16(w[1] ^ kBias, kBias, amp);
         }
         const uint32_t md = div_exact(mark, (uint32_t)bf, rcp_bf), sd = div_exact(space, (uint32_t)bf, rcp_bf);
-        const bool bit = md < sd;
-        const bool loud = amp >= amp_thr;
+        const bool bit = md < sd;                                              // ref:348-351
+        const bool loud = amp >= amp_thr;                                      // ref:375
         const uint64_t bmask = __ballot(bit && lane < spr);
         const uint64_t amask = __ballot(loud && lane < spr);
         const int k0 = r * spr;
         if (margins && lane < spr && k0 + lane < K && k0 + lane < margin_stride)
             margins[k0 + lane] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < spr ? (K - k0) : spr;
-        // all lanes must have finished reading before the next round overwrites the slot
+        // every lane's reads of this slot have returned before round r+2 overwrites it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rx_consume(st, bmask, amask, nv, k0, lane, out_row, out_stride);
         if (st.phase == 2) break;
