@@ -48,6 +48,12 @@ static void launch_lib(const DemodArgs& a, hipStream_t s) {
     g_lib_demod(a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
                 a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
 }
+// a second build of the library (KBENCH_LIB_B=<path>): A/B of two source revisions in one process
+static lib_demod_fn g_lib_demod_b = nullptr;
+static void launch_lib_b(const DemodArgs& a, hipStream_t s) {
+    g_lib_demod_b(a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
+                  a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
+}
 
 struct Variant { const char* name; launch_fn fn; bool exact; };
 
@@ -159,6 +165,14 @@ int main(int argc, char** argv) {
     if (void* h = dlopen("../afskmodem_amd/csrc/libafsk_amd.so", RTLD_NOW)) {
         g_lib_demod = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
         if (g_lib_demod) vs.insert(vs.begin() + 2, Variant{"libafsk_amd.so entry", launch_lib, true});
+    }
+    if (const char* pb = getenv("KBENCH_LIB_B")) {
+        if (void* h = dlopen(pb, RTLD_NOW | RTLD_LOCAL)) {
+            g_lib_demod_b = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
+            if (g_lib_demod_b) vs.insert(vs.begin() + 3, Variant{"lib B entry", launch_lib_b, true});
+        } else {
+            printf("cannot load %s: %s\n", pb, dlerror());
+        }
     }
     if (const char* only = getenv("KBENCH_ONLY")) {          // run a single variant (cache-state studies)
         std::vector<Variant> keep;
