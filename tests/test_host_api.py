@@ -178,6 +178,40 @@ def test_cabi_argument_checks():
     assert rc == _native.E_INVALID_BAUD
 
 
+def test_cabi_argument_checks_new_entries():
+    """afsk_demod_batch_ex / afsk_demod_streams_host / afsk_host_scratch_release: argument
+    validation happens before any device call, so it is checkable without a GPU."""
+    lib = _native.lib()
+    none14 = [None] * 4 + [14000]
+    rc = lib.afsk_demod_batch_ex(*none14, 4, None, 0, None, None, None, None, None, None, None, -1, None)
+    assert rc == _native.E_INVALID_ARG and "negative" in _native.last_error()
+    assert lib.afsk_demod_batch_ex(*none14, 0, None, 0, None, None, None, None, None, None, None, 0,
+                                   None) == 0
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))  # noqa: E731
+    x = np.zeros(5000, np.int16)
+    ptrs = (ctypes.c_void_p * 1)(x.ctypes.data)
+    ob = np.zeros(8, np.uint8); i32 = [np.zeros(1, np.int32) for _ in range(5)]
+    outs = (p(ob, ctypes.c_uint8), 8, *(p(a, ctypes.c_int32) for a in i32))
+    ln = np.array([5000], np.int32)
+    for bad_bf in (10, 0, 2048):
+        bf = np.array([bad_bf], np.int32)
+        assert lib.afsk_demod_streams_host(ptrs, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
+                                           *outs) == _native.E_INVALID_BAUD
+    bf = np.array([40], np.int32)
+    neg = np.array([-1], np.int32)
+    assert lib.afsk_demod_streams_host(ptrs, p(neg, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
+                                       *outs) == _native.E_INVALID_ARG
+    null = (ctypes.c_void_p * 1)(None)
+    assert lib.afsk_demod_streams_host(null, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
+                                       *outs) == _native.E_INVALID_ARG
+    assert lib.afsk_demod_streams_host(None, None, None, 14000, 0, None, 0, None, None, None, None,
+                                       None) == 0
+    if _native.device_count() == 0:
+        assert lib.afsk_demod_streams_host(ptrs, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000,
+                                           1, *outs) == _native.E_NO_DEVICE
+    assert lib.afsk_host_scratch_release() == 0           # nothing cached: still fine
+
+
 def test_product_package_never_imports_oracle():
     """The oracle is test infrastructure: nothing under afskmodem_amd/ may reference it."""
     pkg = os.path.join(ROOT, "afskmodem_amd")
