@@ -253,6 +253,115 @@ __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* p
     return (int)__builtin_amdgcn_readfirstlane(cand);
 }
 
+// ---- phase A, lane-wise form (bit_frames 20 / 40) ----------------------------------------
+// Every lane owns GC = 72 CONSECUTIVE sync offsets and the GC + 2*BF raw samples they touch,
+// loaded once from the ring into registers (19 / 14 ds_read_b128; the 144-byte lane stride
+// makes them bank-conflict free).  Against the full-scale square template no abs is needed:
+//   total(i) = 65535*BF + sum_j sigma_j * x[i+j],  sigma_j = -1 where the template is 32767,
+//                                                            +1 where it is -32768,
+// so the first offset of a lane is N/2 v_dot2 and every further offset slides by
+//   total(i+1) - total(i) = x[i] - 2x[i+Q] + 2x[i+2Q] - 2x[i+3Q] + 2x[i+BF] - 2x[i+BF+H] + x[i+N]
+// = 7 v_dot2c_i32_i16 with a (coef, 0) / (0, coef) constant picking the half of the dword.
+// No prefix sums, no cross-lane scan, no window in LDS: 28 KB of LDS reads per stream instead
+// of ~130 KB, and ~40 % fewer VALU instructions than the prefix-window form above.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int BF>
+struct LaneSync {
+    static constexpr int N = 2 * BF, Q = BF / 4, H = BF / 2;
+    static constexpr int NOFF = kSync - N;                     // ref:327
+    static constexpr int GC = 72;                              // offsets per lane
+    static constexpr int WD = (GC + N) / 2;                    // dwords in a lane's sample window
+    static constexpr int LANES = (NOFF + GC - 1) / GC;         // lanes that own valid offsets
+    static constexpr int KMIN = NOFF - GC * (LANES - 1);       // last lane: offsets k >= KMIN are invalid
+    static_assert(WD % 4 == 0 && (GC * 2) % 16 == 0, "window must be whole 16-byte reads");
+    static_assert(LANES <= 64 && GC * (LANES - 1) * 2 + WD * 4 <= kRingBytes, "window outside the ring");
+    // sigma of template position j (ref:80-91: mark = hi,lo,hi,lo quarters, then space = hi,lo halves)
+    static constexpr int sigma(int j) {
+        return j < BF ? ((((j / Q) & 1) == 0) ? -1 : 1) : ((j - BF) < H ? -1 : 1);
+    }
+    static constexpr uint32_t sigma_pair(int d) {
+        return ((uint32_t)(uint16_t)(int16_t)sigma(2 * d)) | ((uint32_t)(uint16_t)(int16_t)sigma(2 * d + 1) << 16);
+    }
+};
+
+__device__ __forceinline__ int32_t dot2_i16(uint32_t pair, uint32_t coef, int32_t acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, coef), acc, false);
+}
+
+template <int BF, bool DEBUG = false>
+__device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t* dbg = nullptr,
+                                                         unsigned long long* stamps = nullptr) {
+    using L = LaneSync<BF>;
+    using G = SyncGeom<BF>;
+    constexpr int N = L::N, Q = L::Q, H = L::H, GC = L::GC, WD = L::WD, NOFF = L::NOFF;
+    constexpr uint32_t C = 65535u * (uint32_t)BF;
+    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);     // floor(m / N) = mul_hi(m, M) >> 4
+    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
+    const int lane = fr.lane;
+    using std::integral_constant;
+
+    wait_vmcnt<G::SYNC_CHUNKS - 8>();                         // chunks 0..7 (samples 0..4095) have landed
+    if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    const int ll = lane < L::LANES ? lane : L::LANES - 1;    // idle lanes re-read the last window
+    const uint8_t* src = fr.ring + (GC * 2) * ll;
+    uint32_t R[WD];
+#pragma unroll
+    for (int j = 0; j < WD / 4; j++) {
+        const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
+        R[4 * j] = t4[0]; R[4 * j + 1] = t4[1]; R[4 * j + 2] = t4[2]; R[4 * j + 3] = t4[3];
+    }
+    // first offset of the lane: the full 2*BF-sample correlation
+    int32_t acc = 0;
+    static_for<0, N / 2>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        acc = dot2_i16(R[d], L::sigma_pair(d), acc);
+    });
+    // lanes without valid offsets start far above any real total (|sum of deltas| < 2^25)
+    uint32_t total = lane < L::LANES ? C + (uint32_t)acc : 0xF0000000u;
+    const bool last_lane = lane >= L::LANES - 1;
+    uint32_t totals[GC];
+    uint32_t min_total = 0xFFFFFFFFu;
+    static_for<0, GC>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k > 0) {
+            // x[m] = half (m & 1) of R[m >> 1]; coefficient placed in the matching half
+            constexpr int i = k - 1;
+            auto term = [&](auto mc, auto cc, int32_t a) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int c = decltype(cc)::value;
+                constexpr uint32_t coef = (m & 1) ? ((uint32_t)(uint16_t)(int16_t)c << 16) : (uint32_t)(uint16_t)(int16_t)c;
+                return dot2_i16(R[m >> 1], coef, a);
+            };
+            int32_t dl = 0;
+            dl = term(integral_constant<int, i>{}, integral_constant<int, 1>{}, dl);
+            dl = term(integral_constant<int, i + Q>{}, integral_constant<int, -2>{}, dl);
+            dl = term(integral_constant<int, i + 2 * Q>{}, integral_constant<int, 2>{}, dl);
+            dl = term(integral_constant<int, i + 3 * Q>{}, integral_constant<int, -2>{}, dl);
+            dl = term(integral_constant<int, i + BF>{}, integral_constant<int, 2>{}, dl);
+            dl = term(integral_constant<int, i + BF + H>{}, integral_constant<int, -2>{}, dl);
+            dl = term(integral_constant<int, i + N>{}, integral_constant<int, 1>{}, dl);
+            total += (uint32_t)dl;
+        }
+        uint32_t t = total;
+        if constexpr (k >= L::KMIN) t = last_lane ? 0xFFFFFFFFu : t;      // offsets >= 4096 - 2*BF
+        if constexpr (DEBUG) { if (GC * lane + k < NOFF) dbg[GC * lane + k] = t; }
+        totals[k] = t;
+        min_total = t < min_total ? t : min_total;
+    });
+    // ---- pass 2: first index whose mean int(total / N) is minimal (strict <, ref:332-337)
+    const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
+    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
+    uint32_t cand = 0xFFFFFFFFu;
+    static_for<0, GC>([&](auto kc) {
+        constexpr int k = GC - 1 - decltype(kc)::value;                    // last to first: first wins
+        cand = totals[k] < bound ? (uint32_t)k : cand;
+    });
+    cand = cand == 0xFFFFFFFFu ? cand : cand + (uint32_t)(GC * lane);
+    cand = wave_min_u32(cand);
+    return (int)__builtin_amdgcn_readfirstlane(cand);
+}
+
 // ------------------------------------------------------------------ phase B (fast)
 // Re-align 24 dwords (six aligned 16-byte reads) by S bytes into 20 dwords.
 template <int S>
@@ -595,8 +704,11 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     if constexpr (FLAGS & 1) {
         wait_vmcnt<G::SYNC_CHUNKS - 8>();
     } else {
-        ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), nullptr,
-                                          (FLAGS & 64) ? stamps : nullptr);
+        if constexpr (BF <= 80 && !(FLAGS & 8))
+            ci = recover_clock_index_lanes<BF>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
+        else
+            ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), nullptr,
+                                              (FLAGS & 64) ? stamps : nullptr);
     }
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

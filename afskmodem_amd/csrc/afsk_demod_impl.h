@@ -508,6 +508,7 @@ namespace afsk {
 // FLAGS are diagnostic only (tools/kbench.hip); the product instantiates FLAGS = 0.
 constexpr int kFlagSkipSync = 1;    // force clock index 0, no phase A (results wrong unless ci == 0)
 constexpr int kFlagSkipValu = 2;
+constexpr int kFlagOldSync = 8;     // bit_frames 20 / 40: prefix-window clock recovery instead of the lane-wise one
 constexpr int kFlagNoNt = 4;        // default cache policy instead of non-temporal (nt) ring DMA loads    // phase B streams the ring but skips the per-sample VALU work
 
 // FAST = use the stream-aligned single-pass path (afsk_demod_fast.h) for bit_frames 20/40/160;

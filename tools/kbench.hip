@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs = {
         {"v1 two-pass", launch_flags<0, false>, true},
         {"v2 fast (nt)", launch_flags<0, true>, true},
+        {"v2 prefix-window sync", launch_flags<8, true>, true},
         {"v2 fast default-policy", launch_flags<4, true>, true},
         {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
         {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},

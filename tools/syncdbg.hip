@@ -16,7 +16,9 @@ __global__ __launch_bounds__(64) void k_sync(const int16_t* xs, int32_t len, uin
     using G = afsk::SyncGeom<BF>;
     for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.issue(c);
     fr.next = G::SYNC_CHUNKS;
-    int ci = afsk::recover_clock_index_fast<BF, true>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), dbg);
+    int ci;
+    if constexpr (BF <= 80) ci = afsk::recover_clock_index_lanes<BF, true>(fr, dbg);
+    else ci = afsk::recover_clock_index_fast<BF, true>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), dbg);
     afsk::wait_vmcnt<0>();
     if (threadIdx.x == 0) *ci_out = ci;
 }
@@ -50,6 +52,11 @@ int main() {
     std::vector<int16_t> x(6000);
     unsigned s = 12345;
     for (auto& v : x) { s = s * 1664525u + 1013904223u; v = (int16_t)(s >> 16); }
-    run<20>(x); run<40>(x); run<160>(x);
+    run<20>(x); run<40>(x); run<80>(x); run<160>(x);
+    // a Transmitter-like stream: clean training cycles (many equal minima, first one wins)
+    for (size_t i = 0; i < x.size(); i++) { int ph = (int)(i % 80); x[i] = ph < 40 ? (((ph / 10) & 1) ? -32768 : 32767) : (ph < 60 ? 32767 : -32768); }
+    run<40>(x);
+    for (size_t i = 0; i < x.size(); i++) { int ph = (int)((i + 13) % 40); x[i] = (int16_t)((ph < 20 ? (((ph / 5) & 1) ? -30000 : 30000) : (ph < 30 ? 30000 : -30000)) + (int)(i % 7) - 3); }
+    run<20>(x);
     return 0;
 }
