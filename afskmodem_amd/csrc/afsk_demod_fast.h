@@ -289,11 +289,10 @@ __device__ __forceinline__ int32_t dot2_i16(uint32_t pair, uint32_t coef, int32_
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, coef), acc, false);
 }
 
-template <int BF, bool DEBUG = false>
+template <int BF, bool DEBUG = false, int PRE = kRingChunks>
 __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t* dbg = nullptr,
                                                          unsigned long long* stamps = nullptr) {
     using L = LaneSync<BF>;
-    using G = SyncGeom<BF>;
     constexpr int N = L::N, Q = L::Q, H = L::H, GC = L::GC, WD = L::WD, NOFF = L::NOFF;
     constexpr uint32_t C = 65535u * (uint32_t)BF;
     constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);     // floor(m / N) = mul_hi(m, M) >> 4
@@ -301,7 +300,7 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     const int lane = fr.lane;
     using std::integral_constant;
 
-    wait_vmcnt<G::SYNC_CHUNKS - 8>();                         // chunks 0..7 (samples 0..4095) have landed
+    wait_vmcnt<PRE - 8>();                                    // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
     const int ll = lane < L::LANES ? lane : L::LANES - 1;    // idle lanes re-read the last window
     const uint8_t* src = fr.ring + (GC * 2) * ll;
@@ -358,6 +357,98 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
         cand = totals[k] < bound ? (uint32_t)k : cand;
     });
     cand = cand == 0xFFFFFFFFu ? cand : cand + (uint32_t)(GC * lane);
+    cand = wave_min_u32(cand);
+    return (int)__builtin_amdgcn_readfirstlane(cand);
+}
+
+// ---- phase A, lane-wise form in steps (bit_frames 160) -----------------------------------
+// A 300-baud lane window (72 + 320 samples) does not fit the register file, so the search runs
+// in steps of 64 * GC offsets with GC = 24 per lane: a lane loads only the seven GC-sample
+// sub-windows its deltas touch (7 x 3 ds_read_b128; all seven lags are multiples of 8
+// samples, the 48-byte lane stride is bank-conflict free), forms the GC deltas with 7
+// v_dot2c_i32_i16 each and their running sum; the total at a lane's first offset is the step's
+// base plus the exclusive wave scan of the lane sums (one DPP scan per step), and the base of
+// the next step is the base plus the scan's last element.  Only offset 0 needs a full
+// correlation: 40 lanes take 8 samples each (8 divides the quarter symbol, so a lane's samples
+// share one sign) and a wave reduction adds them up.
+template <int BF, bool DEBUG = false, int PRE = kRingChunks>
+__device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint32_t* dbg = nullptr,
+                                                              unsigned long long* stamps = nullptr) {
+    constexpr int N = 2 * BF, Q = BF / 4, H = BF / 2, NOFF = kSync - N;
+    constexpr int GC = 24, STEP = 64 * GC, T = (NOFF + STEP - 1) / STEP;
+    static_assert(Q % 8 == 0, "lags must be multiples of 8 samples (16-byte reads)");
+    static_assert(N % 8 == 0 && N / 8 <= 64, "offset 0 is correlated 8 samples per lane");
+    static_assert(2 * (STEP * (T - 1) + GC * 63 + N + GC) <= kRingBytes, "sub-windows outside the ring");
+    constexpr uint32_t C = 65535u * (uint32_t)BF;
+    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
+    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
+    const int lane = fr.lane;
+    using std::integral_constant;
+
+    wait_vmcnt<PRE - 8>();                                    // chunks 0..7 (samples 0..4095) have landed
+    if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    // total(0) = C + sum_j sigma_j x[j]: lane l < N/8 takes samples 8l .. 8l+7 (one sign)
+    uint32_t base;
+    {
+        const int j0 = 8 * (lane < N / 8 ? lane : 0);
+        const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + 2 * j0);
+        int32_t a = 0;
+        a = dot2_i16(t4[0], 0x00010001u, a); a = dot2_i16(t4[1], 0x00010001u, a);
+        a = dot2_i16(t4[2], 0x00010001u, a); a = dot2_i16(t4[3], 0x00010001u, a);
+        const bool hi = j0 < BF ? (((j0 / Q) & 1) == 0) : ((j0 - BF) < H);     // template is 32767 here
+        a = lane < N / 8 ? (hi ? -a : a) : 0;
+        const int32_t sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(a), 63);
+        base = C + (uint32_t)sum;
+    }
+    uint32_t totals[T * GC];
+    uint32_t min_total = 0xFFFFFFFFu;
+    static_for<0, T>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const uint8_t* src = fr.ring + 2 * (STEP * t + GC * lane);
+        constexpr int lag[7] = {0, Q, 2 * Q, 3 * Q, BF, BF + H, N};
+        constexpr int coef[7] = {1, -2, 2, -2, 2, -2, 1};
+        uint32_t R[7][GC / 2];
+#pragma unroll
+        for (int e = 0; e < 7; e++) {
+#pragma unroll
+            for (int j = 0; j < GC / 8; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 2 * lag[e] + 16 * j);
+                R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
+            }
+        }
+        // run[k] = total(first + k + 1) - total(first)
+        int32_t run[GC];
+        int32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+#pragma unroll
+            for (int e = 0; e < 7; e++) {
+                const uint32_t c = (uint32_t)(uint16_t)(int16_t)coef[e];
+                acc = dot2_i16(R[e][k >> 1], (k & 1) ? (c << 16) : c, acc);
+            }
+            run[k] = acc;
+        }
+        const int32_t incl = wave_incl_scan_dpp(acc);
+        const uint32_t first = base + (uint32_t)(incl - acc);          // total at this lane's first offset
+        base += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+            uint32_t tot = k == 0 ? first : first + (uint32_t)run[k - 1];
+            const int i = STEP * t + GC * lane + k;
+            if constexpr (STEP * t + STEP > NOFF) tot = i < NOFF ? tot : 0xFFFFFFFFu;
+            if constexpr (DEBUG) { if (i < NOFF) dbg[i] = tot; }
+            totals[t * GC + k] = tot;
+            min_total = tot < min_total ? tot : min_total;
+        }
+    });
+    const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
+    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
+    uint32_t cand = 0xFFFFFFFFu;
+    static_for<0, T * GC>([&](auto kc) {
+        constexpr int k = T * GC - 1 - decltype(kc)::value;                // last to first: first wins
+        constexpr int i0 = STEP * (k / GC) + (k % GC);                     // offset of lane 0
+        cand = totals[k] < bound ? (uint32_t)(i0 + GC * lane) : cand;
+    });
     cand = wave_min_u32(cand);
     return (int)__builtin_amdgcn_readfirstlane(cand);
 }
@@ -512,6 +603,37 @@ __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, u
     }
 }
 
+// Sum of a value over the 2 or 4 lanes of a quad-aligned group, result in every lane (DPP).
+template <int LPS>
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    static_assert(LPS == 2 || LPS == 4, "two or four lanes per symbol");
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    if constexpr (LPS == 4)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    return v;
+}
+
+// Bits 0, LPS, 2*LPS, ... of a wave-uniform mask packed into the low 64 / LPS bits (scalar unit).
+template <int LPS>
+__device__ __forceinline__ uint64_t compress_bits(uint64_t x) {
+    if constexpr (LPS == 2) {
+        x &= 0x5555555555555555ull;
+        x = (x | (x >> 1)) & 0x3333333333333333ull;
+        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+        x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    } else {
+        static_assert(LPS == 4, "two or four lanes per symbol");
+        x &= 0x1111111111111111ull;
+        x = (x | (x >> 3)) & 0x0303030303030303ull;
+        x = (x | (x >> 6)) & 0x000F000F000F000Full;
+        x = (x | (x >> 12)) & 0x000000FF000000FFull;
+        x = (x | (x >> 24)) & 0x000000000000FFFFull;
+    }
+    return x;
+}
+
 // One 5 KiB round: symbol decisions, then (only once the training terminator has been
 // seen) squelch amplitudes, Hamming decode and byte pack.
 template <int BF, int FLAGS>
@@ -598,23 +720,20 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             mark = ha + (FULL * Q - hb);                           // quarters 2*part (even), 2*part+1 (odd)
             space = part == 0 ? ha + hb : 2u * FULL * Q - ha - hb;
         }
-#pragma unroll
-        for (int s = 1; s < LPS; s <<= 1) {
-            mark += (uint32_t)__shfl_xor((int)mark, s, 64);
-            space += (uint32_t)__shfl_xor((int)space, s, 64);
-        }
+        // sum over the LPS lanes of a symbol with DPP quad permutes (VALU only; __shfl_xor would
+        // be a ds_bpermute round trip through the LDS pipe per step)
+        mark = quad_sum<LPS>(mark);
+        space = quad_sum<LPS>(space);
         const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
-        const bool bit = md < sd;
+        const bool bit = md < sd;                                  // same in all LPS lanes of the symbol
         if (margins && part == 0 && k0 + lane / LPS < mlim)
             margins[k0 + lane / LPS] = (int32_t)sd - (int32_t)md;
-        const int srcl = (lane * LPS) & 63;                        // lane j < SPP <- symbol j
         const int nv = (K - k0) < SPP ? (K - k0) : SPP;
-        const uint64_t bmask = __ballot(__shfl((int)bit, srcl, 64) && lane < SPP);
+        // every LPS-th bit of the ballot, compacted on the scalar unit: bit j <- symbol j
+        const uint64_t bmask = compress_bits<LPS>(__ballot(bit));
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
-            uint32_t amp = abs_sum<0, 20>(x);
-#pragma unroll
-            for (int s = 1; s < LPS; s <<= 1) amp += (uint32_t)__shfl_xor((int)amp, s, 64);
-            return (uint64_t)__ballot(__shfl((int)(amp >= amp_thr), srcl, 64) && lane < SPP);
+            const uint32_t amp = quad_sum<LPS>(abs_sum<0, 20>(x));
+            return compress_bits<LPS>(__ballot(amp >= amp_thr));
         });
     }
 }
@@ -696,16 +815,21 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     fr.ring = lds;
     fr.lane = lane;
     using G = SyncGeom<BF>;
+    // the lane-wise clock recovery needs no LDS of its own: the whole ring is requested at once
+    // (the prefix-window form of kbench's FLAGS & 8 keeps its window in ring slots 12..15 for BF > 64)
+    constexpr int PRE = (FLAGS & 8) ? G::SYNC_CHUNKS : kRingChunks;
 #pragma unroll
-    for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
-    fr.next = G::SYNC_CHUNKS;
+    for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
+    fr.next = PRE;
 
     int ci = 0;
     if constexpr (FLAGS & 1) {
-        wait_vmcnt<G::SYNC_CHUNKS - 8>();
+        wait_vmcnt<PRE - 8>();
     } else {
         if constexpr (BF <= 80 && !(FLAGS & 8))
-            ci = recover_clock_index_lanes<BF>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
+            ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
+        else if constexpr (!(FLAGS & 8))
+            ci = recover_clock_index_lane_steps<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else
             ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), nullptr,
                                               (FLAGS & 64) ? stamps : nullptr);

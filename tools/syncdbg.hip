@@ -17,8 +17,8 @@ __global__ __launch_bounds__(64) void k_sync(const int16_t* xs, int32_t len, uin
     for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.issue(c);
     fr.next = G::SYNC_CHUNKS;
     int ci;
-    if constexpr (BF <= 80) ci = afsk::recover_clock_index_lanes<BF, true>(fr, dbg);
-    else ci = afsk::recover_clock_index_fast<BF, true>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), dbg);
+    if constexpr (BF <= 80) ci = afsk::recover_clock_index_lanes<BF, true, G::SYNC_CHUNKS>(fr, dbg);
+    else ci = afsk::recover_clock_index_lane_steps<BF, true, G::SYNC_CHUNKS>(fr, dbg);
     afsk::wait_vmcnt<0>();
     if (threadIdx.x == 0) *ci_out = ci;
 }
