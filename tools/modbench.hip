@@ -1,8 +1,10 @@
 // modbench.hip -- store-roof probes for the modulator (diagnostic, not product).
 //   ./modbench [n_streams=4096]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../afskmodem_amd/csrc/afsk_synth.hip"   // the kernels as templates (diagnostic build)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
@@ -80,6 +82,16 @@ int main(int argc, char** argv) {
         for (int quirk : {1, 0}) {
             afsk::ModulateArgs m{d_payload, plen_v, d_pl, d_bf, d_ts, d_off, d_len, n, quirk, d_x, 0};
             char nm[64];
+            typedef int (*mod_fn)(const uint8_t*, int32_t, const int32_t*, const int32_t*, const int32_t*, const int64_t*,
+                                  const int32_t*, int32_t, int32_t, int32_t, int16_t*, void*);
+            for (const char* path : {(const char*)"../afskmodem_amd/csrc/libafsk_amd.so", (const char*)getenv("MODBENCH_LIB_B")}) {
+                if (!path) continue;
+                void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+                mod_fn f = h ? (mod_fn)dlsym(h, "afsk_modulate_batch") : nullptr;
+                if (!f) { printf("cannot load %s\n", path); continue; }
+                snprintf(nm, 64, "lib %.18s %d q=%d", strrchr(path, '/') ? strrchr(path, '/') + 1 : path, baud, quirk);
+                rep(nm, time_us([&] { f(d_payload, plen_v, d_pl, d_bf, d_ts, d_off, d_len, L, n, quirk, d_x, nullptr); }, 20));
+            }
             snprintf(nm, 64, "modulate %d baud quirk=%d iters=2", baud, quirk);
             rep(nm, time_us([&] { CK(afsk::launch_modulate_t<2>(m, L, 0)); }));
             snprintf(nm, 64, "modulate %d baud quirk=%d iters=4", baud, quirk);
