@@ -34,8 +34,8 @@ __device__ __forceinline__ uint32_t hamming_codeword(uint32_t nib) {
 
 constexpr int kModThreads = 256;
 constexpr int kModIters = 8;                                   // 16-byte stores per thread (product)
-constexpr int mod_chunk(int iters) { return kModThreads * 8 * iters; }   // samples per block
-constexpr int kWinBytes = 2 * kModThreads;                     // payload window of one block
+constexpr int mod_chunk(int iters, int threads = kModThreads) { return threads * 8 * iters; }   // samples per block
+constexpr int kWinBytes = 512;                                 // payload window of one block (power of two)
 
 // Branch-free tone kind of symbol S (true = mark).  `win` is the block's payload window in
 // LDS: win[k] = payload[first_byte + k].
@@ -53,7 +53,7 @@ __device__ __forceinline__ bool symbol_is_mark(uint32_t S, uint32_t n_train_sym,
     return train ? ((S & 1u) == 0) : (term ? (t == 0u) : data_bit);
 }
 
-constexpr int q_words(int iters) { return mod_chunk(iters) / 32 + 16; }   // quarter-symbol bitmap words
+constexpr int q_words(int chunk) { return chunk / 32 + 16; }   // quarter-symbol bitmap words of a block
 
 constexpr uint32_t kHi2 = 0x7FFF7FFFu, kLo2 = 0x80008000u;    // two samples at +32767 / -32768
 
@@ -98,14 +98,14 @@ __device__ __forceinline__ store16 tone_words(uint32_t x0, uint32_t q, float rcp
 
 // TAIL = the block contains the end of the tones: frames at or past `lim` are zero (lim is even
 // when bit_frames % 4 == 0, so whole dwords switch).
-template <int ITERS, bool QUIRK, bool SMALLQ, bool TAIL>
+template <int ITERS, int THREADS, bool QUIRK, bool SMALLQ, bool TAIL>
 __device__ __forceinline__ void tone_block(int16_t* dst0, uint32_t base, uint32_t len, uint32_t phb,
                                            uint32_t q, const uint32_t* qb, uint32_t lim) {
     const float rcp_q = 1.0f / (float)q;
     const uint32_t mq = (65536u + q - 1u) / q;
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const uint32_t local = ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
+        const uint32_t local = ((uint32_t)it * THREADS + threadIdx.x) * 8u;
         const uint32_t p0 = base + local;
         if (p0 >= len) break;
         store16 w = tone_words<QUIRK, SMALLQ>(phb + local, q, rcp_q, mq, qb);
@@ -129,14 +129,14 @@ __device__ __forceinline__ void tone_block(int16_t* dst0, uint32_t base, uint32_
 // the payload window (skipped inside the training sequence), a bitmap of the tone kind of every
 // symbol they touch (one ballot per 64 symbols) and from it the quarter-symbol bitmap
 // tone_words() reads.  Positions fit in 32 bits (stream_len < 2^30).
-template <int ITERS>
-__global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a) {
-    constexpr int kModChunk = mod_chunk(ITERS);
+template <int ITERS, int THREADS = kModThreads>
+__global__ __launch_bounds__(THREADS) void modulate_kernel_t(ModulateArgs a) {
+    constexpr int kModChunk = mod_chunk(ITERS, THREADS);
     static_assert(kModChunk / 56 + 4 <= kWinBytes, "payload window too small for the block");
     __shared__ uint8_t win[kWinBytes];
     // tone kind (1 = mark) of every symbol the block touches: at most chunk/4 + 3 symbols
     __shared__ unsigned long long kinds[kModChunk / 4 / 64 + 2];
-    __shared__ uint32_t qbits[q_words(ITERS)];
+    __shared__ uint32_t qbits[q_words(kModChunk)];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const uint32_t len = (uint32_t)a.stream_len[s];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a)
     if (base >= lim) {                                         // tail silence ref:468 + padding
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
-            const uint32_t p0 = base + ((uint32_t)it * kModThreads + threadIdx.x) * 8u;
+            const uint32_t p0 = base + ((uint32_t)it * THREADS + threadIdx.x) * 8u;
             if (p0 >= len) break;
             int16_t* dst = dst0 + p0;
             if (p0 + 8u <= len) {
@@ -182,8 +182,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a)
     const uint32_t last = (base + kModChunk - 1u) / bf + 2u;              // exclusive upper bound + slack
     const uint32_t nsym_blk = last - Sb + 1u;
     if (Sb + nsym_blk > data0) {                                           // block-uniform: data symbols
-#pragma unroll
-        for (uint32_t k = threadIdx.x; k < (uint32_t)kWinBytes; k += kModThreads) {
+        for (uint32_t k = threadIdx.x; k < (uint32_t)kWinBytes; k += THREADS) {
             const uint32_t idx = first_byte + k;
             win[k] = idx < plen ? payload[idx] : (uint8_t)0;
         }
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a)
     // Kind bitmap: bit r = symbol Sb + r.  Each wave ballots 64 consecutive symbols per pass.
     {
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        for (uint32_t r0 = wave * 64u; r0 < nsym_blk; r0 += kModThreads) {
+        for (uint32_t r0 = wave * 64u; r0 < nsym_blk; r0 += THREADS) {
             const uint32_t S = Sb + r0 + lane;
             const bool mk = S < n_sym && symbol_is_mark(S, n_train_sym, first_byte, win);
             const unsigned long long m = __ballot(mk);
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a)
     {
         // quarter bitmap: word w = symbols Sb + 8w .. 8w+7, 4 bits each: space 0b0011, mark 0b0101
         const uint32_t nwords = (nsym_blk + 7u) >> 3;
-        for (uint32_t w = threadIdx.x; w <= nwords; w += kModThreads) {
+        for (uint32_t w = threadIdx.x; w <= nwords; w += THREADS) {
             uint32_t x = w < nwords ? (uint32_t)(kinds[w >> 3] >> ((w & 7u) * 8u)) & 0xFFu : 0u;
             x = (x | (x << 12)) & 0x000F000Fu;                   // bit k -> bit 4k
             x = (x | (x << 6)) & 0x03030303u;
@@ -216,8 +215,8 @@ __global__ __launch_bounds__(kModThreads) void modulate_kernel_t(ModulateArgs a)
         const uint32_t q = bf >> 2;
         const bool tail = base + kModChunk + 8u > lim;          // the tones end inside this block
         auto run = [&](auto quirk, auto smallq) {
-            if (tail) tone_block<ITERS, decltype(quirk)::value, decltype(smallq)::value, true>(dst0, base, len, phb, q, qbits, lim);
-            else tone_block<ITERS, decltype(quirk)::value, decltype(smallq)::value, false>(dst0, base, len, phb, q, qbits, lim);
+            if (tail) tone_block<ITERS, THREADS, decltype(quirk)::value, decltype(smallq)::value, true>(dst0, base, len, phb, q, qbits, lim);
+            else tone_block<ITERS, THREADS, decltype(quirk)::value, decltype(smallq)::value, false>(dst0, base, len, phb, q, qbits, lim);
         };
         if (a.wav_quirk) {
             if (q >= 8u) run(std::true_type{}, std::false_type{});
@@ -259,14 +258,14 @@ __global__ __launch_bounds__(256) void noise_kernel(NoiseArgs a) {
     }
 }
 
-template <int ITERS>
+template <int ITERS, int THREADS = kModThreads>
 hipError_t launch_modulate_t(ModulateArgs a, int32_t max_len, hipStream_t stream) {
     if (a.n_streams <= 0 || max_len <= 0) return hipSuccess;
-    const int per_block = mod_chunk(ITERS);
+    const int per_block = mod_chunk(ITERS, THREADS);
     a.chunks = (max_len + per_block - 1) / per_block;
     const int64_t blocks = (int64_t)a.chunks * a.n_streams;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(modulate_kernel_t<ITERS>, dim3((uint32_t)blocks), dim3(kModThreads), 0, stream, a);
+    hipLaunchKernelGGL((modulate_kernel_t<ITERS, THREADS>), dim3((uint32_t)blocks), dim3(THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

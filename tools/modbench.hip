@@ -100,6 +100,14 @@ int main(int argc, char** argv) {
             rep(nm, time_us([&] { CK(afsk::launch_modulate_t<8>(m, L, 0)); }));
             snprintf(nm, 64, "modulate %d baud quirk=%d iters=12", baud, quirk);
             rep(nm, time_us([&] { CK(afsk::launch_modulate_t<12>(m, L, 0)); }));
+            snprintf(nm, 64, "modulate %d q=%d 512thr x4", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<4, 512>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 1024thr x2", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<2, 1024>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 1024thr x1", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<1, 1024>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 512thr x2", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<2, 512>(m, L, 0))); }));
         }
     }
     return 0;
