@@ -122,6 +122,16 @@ def test_gather_host_entry_large_batch_crosses_staging_windows(torch_cuda):
     assert got.status[17] == _native.ST_TOO_SHORT and int((got.status == 0).sum()) >= 890
 
 
+def test_plain_c_caller_decodes_on_the_gpu(torch_cuda, tmp_path):
+    """tests/cabi/cabi_smoke.c: a C program (no Python, no torch, no HIP headers) synthesises a
+    1200-baud stream, calls afsk_demod_batch_host and afsk_demod_streams_host, checks the bytes."""
+    import subprocess
+    from tests.test_host_api import build_cabi_smoke
+    r = subprocess.run([build_cabi_smoke(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "payload 'C-ABI ok'" in r.stdout and r.stdout.strip().endswith("OK")
+
+
 def test_golden_cases_device_entry(golden, torch_cuda):
     """Same cases through afsk_demod_batch on device tensors, one mixed-baud launch."""
     cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]

@@ -212,6 +212,31 @@ def test_cabi_argument_checks_new_entries():
     assert lib.afsk_host_scratch_release() == 0           # nothing cached: still fine
 
 
+def build_cabi_smoke(tmp_path):
+    """Compile tests/cabi/cabi_smoke.c (plain C11, only include/afsk_amd.h) against the library."""
+    import subprocess
+    exe = str(tmp_path / "cabi_smoke")
+    libdir = os.path.join(ROOT, "afskmodem_amd", "csrc")
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-std=c11", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi", "cabi_smoke.c"), "-o", exe, "-L", libdir,
+                    "-lafsk_amd", "-Wl,-rpath," + libdir], check=True, capture_output=True)
+    return exe
+
+
+def test_plain_c_caller_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """The boundary is a C ABI: a C program that includes only include/afsk_amd.h links against
+    libafsk_amd.so; without a GPU the host entry reports AFSK_E_NO_DEVICE (exit code 3)."""
+    import subprocess
+    _native.lib()                                   # make sure the library is built
+    exe = build_cabi_smoke(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if _native.device_count() == 0:
+        assert r.returncode == 3, r.stdout + r.stderr
+        assert "no HIP device" in r.stdout
+    else:
+        assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_product_package_never_imports_oracle():
     """The oracle is test infrastructure: nothing under afskmodem_amd/ may reference it."""
     pkg = os.path.join(ROOT, "afskmodem_amd")
