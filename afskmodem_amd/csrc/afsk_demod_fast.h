@@ -8,18 +8,21 @@
 //   ring      16 x 1 KiB chunks; chunk c (samples 512c .. 512c+511) lives in slot
 //             c & 15; one `buffer_load_dwordx4 ... lds` per chunk, bounds-checked by
 //             a descriptor over the whole stream (tail reads return 0).  All 16 chunks
-//             are requested at once (300 baud: 12, its larger prefix window borrows
-//             slots 12..15 during phase A).
-//   phase A   ref:322-339 on the first 8 chunks as they land (progressive vmcnt):
-//             a producer turns 256 raw samples per step into exclusive prefix sums
-//             (DPP wave scan) kept in a 512/1024-entry circular window; a consumer
-//             step evaluates 256 (128 at 300 baud) sync offsets, 7 window reads each.
+//             are requested at once, before anything else.
+//   phase A   ref:322-339 once chunks 0..7 have landed: lane-wise sliding correlation
+//             (recover_clock_index_lanes / _lane_steps): every lane keeps the raw samples of
+//             its own run of consecutive sync offsets in registers and slides the SAD with 7
+//             v_dot2c_i32_i16 per offset.  The first design (a DPP prefix-sum producer feeding
+//             a circular LDS window, 7 lookups per offset: recover_clock_index_fast) is kept
+//             behind the diagnostic FLAGS & 8 for A/B runs; it was LDS-bandwidth bound.
 //   phase B   ref:342-351: every lane owns an 80-byte piece (40 samples: one
-//             1200-baud symbol, two 2400-baud symbols, a quarter 300-baud symbol) at
-//             ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as six aligned
-//             ds_read_b128 and re-aligned in registers by the wave-uniform shift
+//             1200-baud symbol, two 2400-baud symbols, half a 600-baud or a quarter of a
+//             300-baud symbol) at ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as five
+//             aligned ds_read_b128, or six re-aligned in registers by the wave-uniform shift
 //             (2*ci) & 15 (v_alignbyte).  After the reads of round r the five chunks
 //             it consumed are refilled immediately (11 KiB stay in flight).
+//   phase C   ref:361-378, 145-163, 393-399: terminator scan and squelch stop on wave-uniform
+//             ballot masks; the Hamming decode + byte pack is deferred and vectorised.
 #pragma once
 #include <type_traits>
 
@@ -27,19 +30,6 @@ namespace afsk {
 
 constexpr int kRingBytes = 16384;
 constexpr int kRingChunks = 16;
-
-__device__ __forceinline__ void wait_vmcnt_sw(int n) {
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break;
-        case 14: wait_vmcnt<14>(); break; default: wait_vmcnt<15>(); break;
-    }
-}
 
 // Inclusive wave scan (64 lanes) with DPP: 4 row_shr steps + row_bcast:15 + row_bcast:31.
 __device__ __forceinline__ int32_t wave_incl_scan_dpp(int32_t v) {
@@ -74,7 +64,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// Geometry of the clock search for one baud rate.  Prefix sums live in a circular window
+// Geometry of the prefix-window clock search (first design, FLAGS & 8 only) for one baud rate.
+// Prefix sums live in a circular window
 // of PW int32 entries that occupies ring slots 12..15 while phase A runs (those chunks are
 // requested only afterwards).  A producer step turns 256 raw samples (4 per lane) into prefix
 // sums; a consumer step evaluates OC = 64*GC sync offsets (GC per lane), so the LDS round trip
