@@ -12,6 +12,10 @@ for c in G['decode_cases']:
 xs=[build_input(c) for c in G['decode_cases'][:20]]
 off=np.cumsum([0]+[len(x) for x in xs[:-1]]).astype(np.int64); ln=np.array([len(x) for x in xs],np.int32); bf=np.array([48000//c['baud'] for c in G['decode_cases'][:20]],np.int32)
 O.demod_batch(np.concatenate(xs),off,ln,bf,14000,160,4)
+# soft outputs with a margins row that is too short for the stream (writes must stay inside it)
+for c in G['decode_cases'][:30]:
+    x=build_input(c); r=O.demod_batch_soft(x,[0],[len(x)],[48000//c['baud']],c['amp_end'],out_stride=8,margin_stride=50)
+    assert int(r['corrected'][0])==c['soft']['corrected']
 for c in G['listen_cases']:
     O.gate_stream(build_capture(c['recipe']),c['amp_start'],c['amp_end'],16)
 print("asan run ok", n)
