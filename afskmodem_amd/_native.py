@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafsk_amd.so")
 
 OK = 0
-E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP = -1, -2, -3, -4
+E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP, E_HOST = -1, -2, -3, -4, -5
 ST_OK, ST_TOO_SHORT, ST_NO_DATA, ST_INVALID_BAUD = 0, 1, 2, 3
 
 SAMPLE_RATE = 48000

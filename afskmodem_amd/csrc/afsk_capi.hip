@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -144,6 +146,21 @@ void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
         if (e_ != hipSuccess) { rc = hip_fail(e_, what); goto done; } \
     } while (0)
 
+// The host-buffer entries allocate (std::vector, std::thread): nothing may be thrown across the
+// C boundary, so the bodies live in *_impl and the exported functions catch everything.
+template <class F>
+int no_throw(F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(AFSK_E_HOST, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(AFSK_E_HOST, std::string("host-side failure: ") + e.what());
+    } catch (...) {
+        return fail(AFSK_E_HOST, "host-side failure");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,12 +229,12 @@ int afsk_demod_batch_ex(const int16_t* samples, const int64_t* stream_offset,
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel");
 }
 
-int afsk_demod_batch_host(const int16_t* samples, int64_t total_samples,
-                          const int64_t* stream_offset, const int32_t* stream_len,
-                          const int32_t* bit_frames, int32_t amp_end_threshold,
-                          int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
-                          int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
-                          int32_t* out_term_frame, int32_t* out_status) {
+static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
+                                 const int64_t* stream_offset, const int32_t* stream_len,
+                                 const int32_t* bit_frames, int32_t amp_end_threshold,
+                                 int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
+                                 int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                                 int32_t* out_term_frame, int32_t* out_status) {
     if (n_streams < 0 || out_stride < 0 || total_samples < 0)
         return fail(AFSK_E_INVALID_ARG, "negative size");
     if (n_streams == 0) return AFSK_OK;
@@ -284,6 +301,19 @@ done:
     return rc;   // the lease returns (or frees) the device scratch
 }
 
+int afsk_demod_batch_host(const int16_t* samples, int64_t total_samples,
+                          const int64_t* stream_offset, const int32_t* stream_len,
+                          const int32_t* bit_frames, int32_t amp_end_threshold,
+                          int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
+                          int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                          int32_t* out_term_frame, int32_t* out_status) {
+    return no_throw([&] {
+        return demod_batch_host_impl(samples, total_samples, stream_offset, stream_len, bit_frames,
+                                     amp_end_threshold, n_streams, out_bytes, out_stride, out_nbytes,
+                                     out_nbits, out_clock_idx, out_term_frame, out_status);
+    });
+}
+
 int afsk_host_scratch_release(void) {
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     if (g_scratch.ptr) {
@@ -299,11 +329,11 @@ int afsk_host_scratch_release(void) {
     return AFSK_OK;
 }
 
-int afsk_demod_streams_host(const int16_t* const* streams, const int32_t* stream_len,
-                            const int32_t* bit_frames, int32_t amp_end_threshold,
-                            int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
-                            int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
-                            int32_t* out_term_frame, int32_t* out_status) {
+static int demod_streams_host_impl(const int16_t* const* streams, const int32_t* stream_len,
+                                   const int32_t* bit_frames, int32_t amp_end_threshold,
+                                   int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
+                                   int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                                   int32_t* out_term_frame, int32_t* out_status) {
     if (n_streams < 0 || out_stride < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
     if (n_streams == 0) return AFSK_OK;
     if (!streams || !stream_len || !bit_frames || !out_nbytes || !out_nbits || !out_clock_idx ||
@@ -395,6 +425,18 @@ int afsk_demod_streams_host(const int16_t* const* streams, const int32_t* stream
 done:
     if (rc != AFSK_OK) (void)hipStreamSynchronize(stream);   // nothing may still read the staging windows
     return rc;
+}
+
+int afsk_demod_streams_host(const int16_t* const* streams, const int32_t* stream_len,
+                            const int32_t* bit_frames, int32_t amp_end_threshold,
+                            int32_t n_streams, uint8_t* out_bytes, int32_t out_stride,
+                            int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                            int32_t* out_term_frame, int32_t* out_status) {
+    return no_throw([&] {
+        return demod_streams_host_impl(streams, stream_len, bit_frames, amp_end_threshold, n_streams,
+                                       out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx,
+                                       out_term_frame, out_status);
+    });
 }
 
 int afsk_modulate_batch(const uint8_t* payload, int32_t payload_stride,

@@ -36,6 +36,8 @@ extern "C" {
 #define AFSK_E_INVALID_BAUD (-2) /* bit_frames not a multiple of 4 or 2*bf >= 4096      */
 #define AFSK_E_NO_DEVICE (-3)
 #define AFSK_E_HIP (-4)          /* a HIP runtime call failed, see afsk_last_error      */
+#define AFSK_E_HOST (-5)         /* host-side failure in a host-buffer entry (out of memory,
+                                    thread creation); nothing is thrown across the boundary */
 
 /* per-stream status written to out_status (reference behaviour in brackets) */
 #define AFSK_ST_OK 0
