@@ -337,6 +337,26 @@ def main():
         add_case(f"clean/rand5/{baud}", w.tolist(), baud,
                  gen={"kind": "wav", "payload_hex": data.hex(), "baud": baud,
                       "training_time": 0.5, "total": None})
+    # appended later (fresh generator, so the cases above keep their data): 600 baud with noise,
+    # and pure noise ("garbage") streams -- chance terminators, chance squelch stops, arbitrary
+    # clock indices -- at the four single-pass baud rates
+    rng3 = np.random.default_rng(31337)
+    for snr in (20, 7, 3):
+        data = rng3.integers(0, 256, 16, dtype=np.uint8).tobytes()
+        w = wav_frames(data, 600, 0.5, 48000)
+        q = snr_to_scale_q24(snr)
+        noisy = O.add_noise(w, seed=78, stream_idx=600 + snr, scale_q24=q)
+        add_case(f"noise/600/snr{snr}", noisy.tolist(), 600,
+                 gen={"kind": "wav_noise", "payload_hex": data.hex(), "baud": 600,
+                      "training_time": 0.5, "total": 48000, "seed": 78,
+                      "stream_idx": 600 + snr, "scale_q24": q, "snr_db": snr})
+    for baud in (300, 600, 1200, 2400):
+        for total, scale, amp_end in ((4096, 1 << 24, 14000), (5003, 1 << 22, 14000), (9000, 3 << 20, 14000),
+                                      (7001, 1 << 22, 20000), (12000, 1 << 23, 0), (6000, 1 << 21, 9000)):
+            x = O.add_noise(np.zeros(total, np.int16), seed=4242, stream_idx=baud + total, scale_q24=scale)
+            add_case(f"garbage/{baud}/{total}/{scale}", x.tolist(), baud, amp_end=amp_end,
+                     gen={"kind": "garbage", "total": total, "seed": 4242, "stream_idx": baud + total,
+                          "scale_q24": scale})
     G["decode_cases"] = cases
 
     # ---- 5b. live gate (Receiver.__listen ref:299-319) replayed over finite captures

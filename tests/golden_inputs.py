@@ -41,6 +41,8 @@ def build_input(case: dict) -> np.ndarray:
     elif kind == "wav_noise":
         x = _wav(g["payload_hex"], g["baud"], g["training_time"], g["total"])
         x = O.add_noise(x, g["seed"], g["stream_idx"], g["scale_q24"])
+    elif kind == "garbage":
+        x = O.add_noise(np.zeros(g["total"], np.int16), g["seed"], g["stream_idx"], g["scale_q24"])
     else:
         raise ValueError(kind)
     x = np.ascontiguousarray(x, dtype=np.int16)
