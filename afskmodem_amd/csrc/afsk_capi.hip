@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -123,20 +124,34 @@ void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
         for (const CopyJob& j : jobs) std::memcpy(j.dst, j.src, j.bytes);
         return;
     }
+    // split the byte range into nt contiguous shares
     const size_t share = (total + nt - 1) / nt;
-    std::vector<std::thread> th;
+    std::vector<std::vector<CopyJob>> parts;
     size_t ji = 0, joff = 0;                       // cursor: job index, byte offset inside it
-    for (unsigned t = 0; t < nt && ji < jobs.size(); t++) {
+    while (ji < jobs.size()) {
         std::vector<CopyJob> mine;
         size_t left = share;
         while (left > 0 && ji < jobs.size()) {
             const size_t take = std::min(left, jobs[ji].bytes - joff);
-            mine.push_back({jobs[ji].dst + joff, jobs[ji].src + joff, take});
+            if (take > 0) mine.push_back({jobs[ji].dst + joff, jobs[ji].src + joff, take});
             left -= take; joff += take;
             if (joff == jobs[ji].bytes) { ji++; joff = 0; }
         }
-        th.emplace_back([mine = std::move(mine)] { for (const CopyJob& j : mine) std::memcpy(j.dst, j.src, j.bytes); });
+        parts.push_back(std::move(mine));
     }
+    auto run = [](const std::vector<CopyJob>& v) { for (const CopyJob& j : v) std::memcpy(j.dst, j.src, j.bytes); };
+    // helpers take parts 1.., the caller part 0 and whatever could not get a thread; every
+    // started thread is joined on every path (a joinable std::thread must not be destroyed)
+    std::vector<std::thread> th;
+    size_t spawned = 1;
+    try {
+        th.reserve(parts.size());
+        for (; spawned < parts.size(); spawned++) th.emplace_back(run, std::cref(parts[spawned]));
+    } catch (...) {
+        // no more threads: the rest is copied inline below
+    }
+    if (!parts.empty()) run(parts[0]);
+    for (size_t k = spawned; k < parts.size(); k++) run(parts[k]);
     for (auto& x : th) x.join();
 }
 
