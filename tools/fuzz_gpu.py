@@ -1,0 +1,72 @@
+"""Randomised GPU-vs-oracle comparison, larger than the test suite's (diagnostic).
+   python tools/fuzz_gpu.py [streams_per_config=3000] [seed=1]
+Random-noise streams (uniformly distributed clock indices, chance terminators and squelch
+stops), bursts spliced at random offsets, every single-pass baud rate plus generic ones,
+random stream offsets (2-byte alignment) and squelch thresholds."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from afskmodem_amd import batch  # noqa: E402
+from oracle import afsk_oracle as O  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
+total_bad = 0
+for baud in (1200, 2400, 600, 300, 1000, 4000, 480):
+    bf = 48000 // baud
+    burst = O.wav_convert(O.get_frames(bytes(rng.integers(0, 256, 3, dtype=np.uint8)), baud, 0.03))
+    pieces = []
+    for i in range(n):
+        L = int(rng.integers(4096, 7000))
+        kind = i % 4
+        if kind == 0:
+            x = rng.integers(-32768, 32768, L).astype(np.int16)
+        elif kind == 1:
+            x = (rng.integers(-32768, 32768, L) * int(rng.integers(6, 24)) // 32).astype(np.int16)
+        elif kind == 2:
+            x = (rng.integers(-32768, 32768, L) // 64).astype(np.int16)
+            at = int(rng.integers(0, max(1, L - len(burst))))
+            w = burst[: L - at]
+            x[at: at + len(w)] = w
+        else:
+            x = rng.integers(-600, 600, L).astype(np.int16)
+            at = int(rng.integers(0, 300))
+            w = burst[: L - at]
+            x[at: at + len(w)] = w
+        pieces.append(x)
+    ln = np.array([len(p) for p in pieces], np.int32)
+    gaps = rng.integers(0, 4, len(pieces))
+    off = np.concatenate([[1], 1 + np.cumsum(ln[:-1] + gaps[:-1])]).astype(np.int64)
+    flat = np.zeros(int(off[-1] + ln[-1] + 8), np.int16)
+    for o, p in zip(off, pieces):
+        flat[o: o + len(p)] = p
+    bfa = np.full(len(pieces), bf, np.int32)
+    for amp_end in (14000, 0, 22000):
+        t0 = time.time()
+        want = O.demod_batch(flat, off, ln, bfa, amp_end, out_stride=64, n_threads=os.cpu_count() or 8)
+        x = torch.from_numpy(flat).cuda()
+        res = batch.demod_batch(x, torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), bfa, amp_end,
+                                out_stride=64)
+        torch.cuda.synchronize()
+        got = res.cpu()
+        bad = 0
+        for f in FIELDS:
+            bad += int((getattr(got, f) != want[f]).sum())
+        nb = np.minimum(want["nbytes"], 64)
+        mask = np.arange(64)[None, :] < nb[:, None]
+        bad += int(((got.bytes != want["bytes"]) & mask).any(axis=1).sum())
+        late = int((want["clock_idx"] >= 4096 - 2 * bf - 72).sum())
+        print(f"baud {baud:5d} amp_end {amp_end:5d}: {len(pieces)} streams, mismatching fields {bad}, "
+              f"decoding {int((want['nbits'] > 0).sum())}, clock idx in the last 72 offsets {late} "
+              f"({time.time() - t0:.1f} s)", flush=True)
+        total_bad += bad
+print("TOTAL MISMATCHES", total_bad)
+sys.exit(1 if total_bad else 0)
