@@ -456,6 +456,18 @@ __device__ __forceinline__ void realign(const uint32_t (&W)[24], uint32_t (&x)[2
     }
 }
 
+// Same for NI aligned dwords -> NO dwords (the 8-byte-aligned pieces of the 2400-baud mapping).
+template <int S, int NI, int NO>
+__device__ __forceinline__ void realign_n(const uint32_t (&W)[NI], uint32_t (&x)[NO]) {
+    constexpr int A = S / 4, B = S % 4;
+    static_assert(NO + A + (B ? 1 : 0) <= NI, "not enough input dwords");
+#pragma unroll
+    for (int d = 0; d < NO; d++) {
+        if constexpr (B == 0) x[d] = W[d + A];
+        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
+    }
+}
+
 // Sum over the dwords [D0, D1) of |0xFFFF - limited(x)| per 16-bit half: the SAD of the
 // limited samples against a "hi" (32767) template.  Against a "lo" (-32768) template the
 // SAD of the same samples is 65535 * n_samples minus this, so one v_sad_u16 per dword
@@ -658,7 +670,9 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             if constexpr (!(FLAGS & 2)) amp = abs_sum<0, 20>(x);
             return __ballot(amp >= amp_thr);
         });
-    } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 and 10-19
+    } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 = symbol k0 + lane,
+                                              // dwords 10-19 = symbol k0 + 64 + lane (fast_rounds reads
+                                              // the two 40-byte pieces), so each half is one plain ballot
         uint32_t mk[2] = {0, 0}, sp[2] = {0, 0};
 #pragma unroll
         for (int d = 0; d < 20; d++) {
@@ -671,25 +685,19 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         }
         const uint32_t md0 = mk[0] / (uint32_t)BF, sd0 = sp[0] / (uint32_t)BF;
         const uint32_t md1 = mk[1] / (uint32_t)BF, sd1 = sp[1] / (uint32_t)BF;
-        const int pkb = (int)(md0 < sd0) | ((int)(md1 < sd1) << 1);
+        const bool bit[2] = {md0 < sd0, md1 < sd1};
         if (margins) {
-            const int k = k0 + 2 * lane;
-            if (k < mlim) margins[k] = (int32_t)sd0 - (int32_t)md0;
-            if (k + 1 < mlim) margins[k + 1] = (int32_t)sd1 - (int32_t)md1;
+            if (k0 + lane < mlim) margins[k0 + lane] = (int32_t)sd0 - (int32_t)md0;
+            if (k0 + 64 + lane < mlim) margins[k0 + 64 + lane] = (int32_t)sd1 - (int32_t)md1;
         }
-        int pka = -1;                          // amplitudes computed lazily, once per round
-        // symbol j of this round lives in lane j/2, half j%2: two passes of 64 symbols
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int kk = k0 + 64 * half;
             if (kk >= K || rd.st.phase == 2) break;
             const int nv = (K - kk) < 64 ? (K - kk) : 64;
-            const int vb = __shfl(pkb, 32 * half + (lane >> 1), 64) >> (lane & 1);
-            rxd_pass<64>(rd, __ballot(vb & 1), nv, kk, lane, words, out_row, out_stride, [&]() {
-                if (pka < 0)
-                    pka = (int)(abs_sum<0, 10>(x) >= amp_thr) | ((int)(abs_sum<10, 20>(x) >= amp_thr) << 1);
-                const int va = __shfl(pka, 32 * half + (lane >> 1), 64) >> (lane & 1);
-                return __ballot(va & 1);
+            rxd_pass<64>(rd, __ballot(bit[half]), nv, kk, lane, words, out_row, out_stride, [&]() {
+                const uint32_t amp = half == 0 ? abs_sum<0, 10>(x) : abs_sum<10, 20>(x);
+                return __ballot(amp >= amp_thr);
             });
         }
     } else {                                  // BF = 80 / 160: two / four lanes per symbol
@@ -747,7 +755,38 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         wait_vmcnt<10>();
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
-        if constexpr (ALIGNED) {
+        if constexpr (BF == 20) {
+            // 2400 baud: lane l takes symbol l (bytes 40l .. 40l+39 of the round) and symbol 64 + l
+            // (2560 bytes further): ten 8-byte reads; the 40-byte lane stride spreads 32 lanes over
+            // all 64 banks.  ALIGNED here means (2*ci) & 7 == 0.
+#pragma unroll
+            for (int piece = 0; piece < 2; piece++) {
+                const int pb = rb + 2560 * piece + 40 * lane;
+                if constexpr (ALIGNED) {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((pb + 8 * j) & (kRingBytes - 1)));
+                        x[10 * piece + 2 * j] = t2[0]; x[10 * piece + 2 * j + 1] = t2[1];
+                    }
+                } else {
+                    const int ab = pb & ~7;
+                    uint32_t W[12];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((ab + 8 * j) & (kRingBytes - 1)));
+                        W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
+                    }
+                    uint32_t y[10];
+                    switch (byte0 & 7) {
+                        case 2: realign_n<2, 12, 10>(W, y); break;
+                        case 4: realign_n<4, 12, 10>(W, y); break;
+                        default: realign_n<6, 12, 10>(W, y); break;
+                    }
+#pragma unroll
+                    for (int d = 0; d < 10; d++) x[10 * piece + d] = y[d];
+                }
+            }
+        } else if constexpr (ALIGNED) {
             if (rb + 5120 <= kRingBytes) {                              // no wrap in this round
                 const uint8_t* src = fr.ring + rb + 80 * lane;
 #pragma unroll
@@ -848,7 +887,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
     RxDeferred rd;
     rxd_init(rd);
-    if ((byte0 & 15) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    constexpr int kAlignMask = BF == 20 ? 7 : 15;               // 2400 baud reads 8-byte pieces
+    if ((byte0 & kAlignMask) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     rxd_finish<PS>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
