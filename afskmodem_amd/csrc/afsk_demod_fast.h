@@ -286,8 +286,11 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     using L = LaneSync<BF>;
     constexpr int N = L::N, Q = L::Q, H = L::H, GC = L::GC, WD = L::WD, NOFF = L::NOFF;
     constexpr uint32_t C = 65535u * (uint32_t)BF;
-    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);     // floor(m / N) = mul_hi(m, M) >> 4
-    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
+    // floor(m / N) = mul_hi(m, ceil(2^(32+SH) / N)) >> SH, exact while m * N < 2^(32+SH); m <= 65535 * N
+    constexpr int SH = N <= 16 ? 0 : 4;
+    constexpr uint32_t M = (uint32_t)(((1ull << (32 + SH)) + N - 1) / N);
+    static_assert(N <= 512 && ((1ull << (32 + SH)) + N - 1) / N < (1ull << 32) &&
+                  65535ull * N * N < (1ull << (32 + SH)), "magic divisor out of range");
     const int lane = fr.lane;
     using std::integral_constant;
 
@@ -341,7 +344,7 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     });
     // ---- pass 2: first index whose mean int(total / N) is minimal (strict <, ref:332-337)
     const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
-    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
+    const uint32_t bound = ((__umulhi(m, M) >> SH) + 1u) * (uint32_t)N;    // (min mean + 1) * N
     uint32_t cand = 0xFFFFFFFFu;
     static_for<0, GC>([&](auto kc) {
         constexpr int k = GC - 1 - decltype(kc)::value;                    // last to first: first wins
@@ -832,6 +835,139 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
     }
 }
 
+// ---- other baud rates on the single-pass ring: several whole symbols per lane ------------
+// bit_frames 4 / 8 / 12 / 16 / 24 / 32 / 48 / 64 (12000 ... 750 baud).  A round is R chunks =
+// 64 * SPL symbols; lane l takes symbols l, l + 64, ... (SPL pieces of 2*BF bytes, read with
+// 16-byte loads when BF % 8 == 0, 8-byte loads otherwise), so every 64-symbol slice of the round is
+// one plain ballot -- the 2400-baud scheme with other sizes.  (The remaining valid bit_frames --
+// 60, 96, 100, 120 and above 160 -- have no round of whole chunks that leaves enough of the ring
+// in flight and stay on the two-pass path.)
+template <int BF>
+struct MultiGeom {
+    static constexpr bool valid = BF == 4 || BF == 8 || BF == 12 || BF == 16 || BF == 24 || BF == 32 ||
+                                  BF == 48 || BF == 64;
+    static constexpr int R = BF == 4 || BF == 8 ? 5 : (BF == 32 ? 4 : (BF == 64 ? 8 : 6));   // chunks per round
+    static constexpr int SPL = 8 * R / BF;                     // symbols per lane per round
+    static constexpr int PB = 2 * BF;                          // bytes per symbol
+    static constexpr int RW = BF % 8 == 0 ? 16 : 8;            // bytes per LDS read
+    static constexpr int NO = BF / 2;                          // dwords per symbol
+    static constexpr int SPR = 64 * SPL;                       // symbols per round
+    static_assert(!valid || (SPL * BF == 8 * R && PB % RW == 0 && R + 1 < kRingChunks), "round geometry");
+};
+
+template <int BF, int FLAGS, bool ALIGNED>
+__device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
+                                             uint32_t amp_thr, RxDeferred& rd,
+                                             unsigned long long* words, uint8_t* out_row,
+                                             int out_stride, int32_t* margins, int32_t mstride) {
+    using MG = MultiGeom<BF>;
+    constexpr int R = MG::R, SPL = MG::SPL, PB = MG::PB, RW = MG::RW, NO = MG::NO, SPR = MG::SPR;
+    constexpr int Q = BF / 4, H = BF / 2;
+    constexpr uint32_t FULL = 65535u;
+    constexpr int NR_READS = PB / RW;                          // reads per piece when aligned
+    constexpr int DW = RW / 4;                                 // dwords per read
+    const int lane = fr.lane;
+    const int32_t mlim = K < mstride ? K : mstride;
+    for (int r = 0; r < NR; r++) {
+        // bytes [byte0 + 1024 R r, +1024 R) must have landed: at most R + 1 chunks from the oldest
+        // resident one; chunks through B_r + 15 are issued, so the 15 - R youngest may be in flight
+        wait_vmcnt<kRingChunks - 1 - R>();
+        uint32_t x[SPL * NO];
+        const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
+#pragma unroll
+        for (int piece = 0; piece < SPL; piece++) {
+            const int pb = rb + 64 * PB * piece + PB * lane;
+            if constexpr (ALIGNED) {
+#pragma unroll
+                for (int j = 0; j < NR_READS; j++) {
+                    const uint8_t* p = fr.ring + ((pb + RW * j) & (kRingBytes - 1));
+                    if constexpr (RW == 16) {
+                        const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
+                        x[NO * piece + 4 * j] = t4[0]; x[NO * piece + 4 * j + 1] = t4[1];
+                        x[NO * piece + 4 * j + 2] = t4[2]; x[NO * piece + 4 * j + 3] = t4[3];
+                    } else {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(p);
+                        x[NO * piece + 2 * j] = t2[0]; x[NO * piece + 2 * j + 1] = t2[1];
+                    }
+                }
+            } else {
+                const int ab = pb & ~(RW - 1);
+                uint32_t W[NO + DW];
+#pragma unroll
+                for (int j = 0; j < NR_READS + 1; j++) {
+                    const uint8_t* p = fr.ring + ((ab + RW * j) & (kRingBytes - 1));
+                    if constexpr (RW == 16) {
+                        const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
+                        W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+                    } else {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(p);
+                        W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
+                    }
+                }
+                uint32_t y[NO];
+                switch (byte0 & (RW - 1)) {
+                    case 2: realign_n<2, NO + DW, NO>(W, y); break;
+                    case 4: realign_n<4, NO + DW, NO>(W, y); break;
+                    case 6: realign_n<6, NO + DW, NO>(W, y); break;
+                    default:
+                        if constexpr (RW == 16) {
+                            switch (byte0 & 15) {
+                                case 8: realign_n<8, NO + DW, NO>(W, y); break;
+                                case 10: realign_n<10, NO + DW, NO>(W, y); break;
+                                case 12: realign_n<12, NO + DW, NO>(W, y); break;
+                                default: realign_n<14, NO + DW, NO>(W, y); break;
+                            }
+                        }
+                        break;
+                }
+#pragma unroll
+                for (int d = 0; d < NO; d++) x[NO * piece + d] = y[d];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill right away
+#pragma unroll
+        for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+        fr.next += R;
+
+        const int k0 = r * SPR;
+#pragma unroll
+        for (int piece = 0; piece < SPL; piece++) {
+            const int kk = k0 + 64 * piece;
+            if (kk >= K || rd.st.phase == 2) break;
+            uint32_t mark = 0, space = 0;
+            if constexpr (BF % 8 == 0) {
+                // quarters are whole dwords: SAD against "hi" per quarter gives both correlators
+                uint32_t hq[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int d = 0; d < NO; d++)
+                    hq[d / (Q / 2)] = __builtin_amdgcn_sad_u16(limit_pair_biased(x[NO * piece + d]), 0xFFFFFFFFu,
+                                                              hq[d / (Q / 2)]);
+                mark = 2u * FULL * Q + hq[0] + hq[2] - hq[1] - hq[3];
+                space = 2u * FULL * Q + hq[0] + hq[1] - hq[2] - hq[3];
+            } else {
+#pragma unroll
+                for (int d = 0; d < NO; d++) {
+                    const uint32_t lim = limit_pair_biased(x[NO * piece + d]);
+                    const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
+                    const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
+                    mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
+                    space = __builtin_amdgcn_sad_u16(lim, ts, space);
+                }
+            }
+            const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+            if (margins && kk + lane < mlim) margins[kk + lane] = (int32_t)sd - (int32_t)md;
+            const int nv = (K - kk) < 64 ? (K - kk) : 64;
+            rxd_pass<64>(rd, __ballot(md < sd), nv, kk, lane, words, out_row, out_stride, [&]() {
+                uint32_t amp = 0;
+#pragma unroll
+                for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[NO * piece + d] ^ kBias, kBias, amp);
+                return __ballot(amp >= amp_thr);
+            });
+        }
+        if (rd.st.phase == 2) break;
+    }
+}
+
 template <int BF, int FLAGS>
 __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
                                                   uint8_t* lds, int lane, RxState& st,
@@ -839,15 +975,16 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   int32_t& n_sym_out,
                                                   unsigned long long* stamps = nullptr,
                                                   int32_t* margins = nullptr, int32_t mstride = 0) {
-    constexpr int SPR = 2560 / BF;                                // symbols per 5 KiB round
+    constexpr bool MULTI = MultiGeom<BF>::valid;
+    constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : 2560 / BF;   // symbols per round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
     fr.lane = lane;
-    using G = SyncGeom<BF>;
     // the lane-wise clock recovery needs no LDS of its own: the whole ring is requested at once
     // (the prefix-window form of kbench's FLAGS & 8 keeps its window in ring slots 12..15 for BF > 64)
-    constexpr int PRE = (FLAGS & 8) ? G::SYNC_CHUNKS : kRingChunks;
+    constexpr bool OLD_SYNC = (FLAGS & 8) && !MULTI;
+    constexpr int PRE = OLD_SYNC ? SyncGeom<MULTI ? 40 : BF>::SYNC_CHUNKS : kRingChunks;
 #pragma unroll
     for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
     fr.next = PRE;
@@ -856,12 +993,12 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     if constexpr (FLAGS & 1) {
         wait_vmcnt<PRE - 8>();
     } else {
-        if constexpr (BF <= 80 && !(FLAGS & 8))
+        if constexpr (BF <= 80 && !OLD_SYNC)
             ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
-        else if constexpr (!(FLAGS & 8))
+        else if constexpr (!OLD_SYNC)
             ci = recover_clock_index_lane_steps<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else
-            ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + G::WIN_OFFSET), nullptr,
+            ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + SyncGeom<BF>::WIN_OFFSET), nullptr,
                                               (FLAGS & 64) ? stamps : nullptr);
     }
     ci_out = ci;
@@ -887,9 +1024,14 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
     RxDeferred rd;
     rxd_init(rd);
-    constexpr int kAlignMask = BF == 20 ? 7 : 15;               // 2400 baud reads 8-byte pieces
-    if ((byte0 & kAlignMask) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-    else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    if constexpr (MULTI) {
+        if ((byte0 & (MultiGeom<BF>::RW - 1)) == 0) multi_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+        else multi_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    } else {
+        constexpr int kAlignMask = BF == 20 ? 7 : 15;               // 2400 baud reads 8-byte pieces
+        if ((byte0 & kAlignMask) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+        else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    }
     rxd_finish<PS>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released

@@ -551,6 +551,10 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
         switch (bf) {
             case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            AFSK_FAST_CASE(4) AFSK_FAST_CASE(8) AFSK_FAST_CASE(12) AFSK_FAST_CASE(16)
+            AFSK_FAST_CASE(24) AFSK_FAST_CASE(32) AFSK_FAST_CASE(48) AFSK_FAST_CASE(64)
+#undef AFSK_FAST_CASE
             case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             default:  done = false; break;

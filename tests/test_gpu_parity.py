@@ -361,13 +361,18 @@ def test_modulator_every_quarter_width(torch_cuda, wav_quirk):
     assert (g2[:1] == 77).all() and (g2[o2[3] + l2[3]:] == 77).all()
 
 
-@pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (512, (600,)), (256, (600, 1200, 300, 2400)), (96, (600, 100, 4000, 6000, 480, 2000))])
+@pytest.mark.parametrize("n,bauds", [(512, (1200,)), (384, (300, 1200, 2400)), (512, (600,)), (256, (600, 1200, 300, 2400)),
+                                     (192, (12000, 6000, 4000, 3000, 2000, 1500, 1000, 750)),
+                                     (128, (12000,)), (128, (750,)), (120, (800, 500, 480, 400, 375, 250)), (96, (600, 100, 4000, 6000, 480, 2000))])
 def test_clean_batches_vs_oracle(torch_cuda, n, bauds):
     """Config #2 / #3 shapes at test size: every output equals the CPU oracle's, and the
     decoded payload equals what was modulated (round trip)."""
     torch = torch_cuda
     pl = None if all(b in synth.ONE_SECOND_PAYLOAD for b in bauds) else 3
-    b = synth_batch(torch, n, bauds, seed=21, payload_len=pl)
+    # the .wav writer's decimate/duplicate quirk (ref:239-244) destroys a 12000-baud mark tone
+    # (quarter symbol = one frame), in the reference too: the pure 12000-baud batch uses ideal frames
+    quirk = bauds != (12000,)
+    b = synth_batch(torch, n, bauds, seed=21, payload_len=pl, wav_quirk=quirk)
     stride = batch.out_stride_for(b["total"], int(b["h_bf"].min()))
     res = batch.demod_batch(b["samples"], b["off"], b["ln"], b["h_bf"], 14000, out_stride=stride)
     torch.cuda.synchronize()
@@ -376,6 +381,8 @@ def test_clean_batches_vs_oracle(torch_cuda, n, bauds):
                          out_stride=stride, n_threads=8)
     assert_same(got, want, f"clean {bauds}")
     for s, data in enumerate(got.payloads()):
+        if quirk and b["h_bf"][s] == 4:
+            continue                      # not decodable after the quirk (GPU == oracle checked above)
         assert data == b["payload"][s, : b["plen"][s]].tobytes(), s
 
 
@@ -565,16 +572,17 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
 
 def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     """The single-pass kernel re-aligns ring reads by (2*ci) & 15: exercise all 8 shifts, ring
-    wrap-around on long streams, and tiny symbol counts, for 300 / 600 / 1200 / 2400 baud."""
+    wrap-around on long streams, and tiny symbol counts, for every baud rate of the single-pass
+    kernel (300 ... 12000 baud)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     pieces, bfs = [], []
-    for baud in (300, 600, 1200, 2400):
+    for baud in (300, 600, 1200, 2400, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750):
         bf = 48000 // baud
         t = afskmodem.Transmitter(baud, 0.1)
         w_short = t.wav_samples(rng.integers(0, 256, 4, dtype=np.uint8).tobytes())
         w_long = afskmodem.Transmitter(baud, 0.3).wav_samples(
-            rng.integers(0, 256, {300: 40, 600: 80, 1200: 160, 2400: 320}[baud], dtype=np.uint8).tobytes())
+            rng.integers(0, 256, min(380, max(40, baud * 2 // 15)), dtype=np.uint8).tobytes())
         for lead in list(range(0, 9)) + [15, 16, 17, 511, 517, 1023, 2047, 3000]:
             pieces.append(np.concatenate([rng.integers(-400, 400, lead).astype(np.int16), w_short]))
             bfs.append(bf)
