@@ -109,7 +109,9 @@ struct SyncGeom {
 constexpr int kWinExtraBytes = 2560;                           // own-LDS window of the BF <= 64 paths
 static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
               "window LDS too small");
-constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave
+constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave with the prefix window (FLAGS & 8)
+constexpr int kBitBufBytes = 512;                              // phase C's 64-word bit buffer behind the ring
+constexpr int kFastWaveLdsProduct = kRingBytes + kBitBufBytes; // 16.5 KiB per wave: what the product build needs
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,

@@ -515,7 +515,7 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 // every other valid bit_frames value takes the two-pass path.
 template <int FLAGS, bool FAST>
 struct KernelCfg {
-    static constexpr int kLdsPerWave = FAST ? (kFastWaveLds > kWaveLds ? kFastWaveLds : kWaveLds) : kWaveLds;
+    static constexpr int kLdsPerWave = FAST ? ((FLAGS & 8) ? kFastWaveLds : kFastWaveLdsProduct) : kWaveLds;
 };
 
 // One stream, start to finish, by one wave.

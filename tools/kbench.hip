@@ -119,6 +119,8 @@ int main(int argc, char** argv) {
         {"v2 fast default-policy", launch_flags<4, true>, true},
         {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
         {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},
+        {"wpb3 lds16.5K (9/CU)", launch_geom<3, 16896>, true},
+        {"wpb1 lds16.5K (9/CU)", launch_geom<1, 16896>, true},
         {"v2 skip_sync", launch_flags<1, true>, true},
         {"v2 skip_valu", launch_flags<2, true>, false},
         {"v2 skip_sync+valu", launch_flags<3, true>, false},
