@@ -68,5 +68,20 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
               f"decoding {int((want['nbits'] > 0).sum())}, clock idx in the last 72 offsets {late} "
               f"({time.time() - t0:.1f} s)", flush=True)
         total_bad += bad
+        if amp_end == 14000:          # soft outputs (afsk_demod_batch_ex) on a slice of the batch
+            m = min(400, len(pieces))
+            ms = 7000 // bf + 1
+            soft = O.demod_batch_soft(flat, off[:m], ln[:m], bfa[:m], amp_end, out_stride=64, margin_stride=ms)
+            r2 = batch.demod_batch(x, torch.from_numpy(off[:m]).cuda(), torch.from_numpy(ln[:m]).cuda(), bfa[:m],
+                                   amp_end, out_stride=64, diagnostics=True, margin_stride=ms)
+            torch.cuda.synchronize()
+            corr = r2.corrected.cpu().numpy()
+            marg = r2.margins.cpu().numpy()
+            nsym = soft["n_symbols"]
+            mask = np.arange(ms)[None, :] < np.minimum(nsym, ms)[:, None]
+            sbad = int((corr != soft["corrected"]).sum()) + int(((marg != soft["margins"]) & mask).any(axis=1).sum())
+            print(f"           soft outputs on {m} streams: mismatches {sbad} "
+                  f"(corrected codewords up to {int(soft['corrected'].max())})", flush=True)
+            total_bad += sbad
 print("TOTAL MISMATCHES", total_bad)
 sys.exit(1 if total_bad else 0)
