@@ -1,0 +1,36 @@
+"""GPU vs oracle on long streams at every single-pass baud rate (diagnostic)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import afskmodem_amd as afskmodem
+from afskmodem_amd import batch
+from oracle import afsk_oracle as O
+afskmodem.LOG_LEVEL = 5
+rng = np.random.default_rng(5)
+bad = 0
+for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 2500, True), (3000, 2000, True), (2400, 1800, True),
+                            (2000, 1500, True), (1500, 1200, True), (1000, 800, True), (750, 600, True), (600, 500, True), (300, 260, True)):
+    bf = 48000 // baud
+    pieces = []
+    for k in range(6):
+        data = rng.integers(0, 256, nbytes + 7 * k, dtype=np.uint8).tobytes()
+        t = afskmodem.Transmitter(baud, 0.05 + 0.01 * k)
+        w = t.wav_samples(data) if quirk else np.concatenate([t.frames(data)])
+        lead = rng.integers(-300, 300, int(rng.integers(0, 50))).astype(np.int16)
+        pieces.append(np.concatenate([lead, w]))
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
+    flat = np.concatenate(pieces)
+    stride = int(nbytes + 64)
+    want = O.demod_batch(flat, off, ln, np.full(6, bf, np.int32), 14000, out_stride=stride, n_threads=6)
+    res = batch.demod_batch(torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), bf, 14000, out_stride=stride).cpu()
+    b = 0
+    for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"):
+        b += int((getattr(res, f) != want[f]).sum())
+    for i in range(6):
+        nb = min(int(want["nbytes"][i]), stride)
+        b += int((res.bytes[i, :nb] != want["bytes"][i, :nb]).any())
+    print(baud, "samples", int(ln.max()), "nbytes", want["nbytes"].tolist(), "mismatches", b, flush=True)
+    bad += b
+print("TOTAL", bad)
