@@ -10,6 +10,7 @@ only), and the call is one asynchronous kernel launch through the C-ABI
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 
 import numpy as np
@@ -29,6 +30,31 @@ def validate_bit_frames(bit_frames) -> None:
         raise IndexError("list index out of range")
     if np.any(bf % 4 != 0):
         raise Exception("Comparing two waveforms of different lengths.")
+
+
+_I32_MAX, _I32_MIN = 2 ** 31 - 1, -2 ** 31
+
+
+def threshold_lt(t) -> int:
+    """int32 T with (a < T) == (a < t) for every integer a: the reference compares the integer
+    amplitude with whatever number the user passed (``int(sum/len) < amp_end_threshold``,
+    ref:375, :316), so a float threshold is rounded UP, never truncated."""
+    t = float(t)
+    if math.isnan(t):
+        return _I32_MIN                  # a < nan is never true
+    if math.isinf(t):
+        return _I32_MAX if t > 0 else _I32_MIN
+    return max(_I32_MIN, min(_I32_MAX, math.ceil(t)))
+
+
+def threshold_gt(t) -> int:
+    """int32 T with (a > T) == (a > t) for every integer a (``> amp_start_threshold``, ref:306)."""
+    t = float(t)
+    if math.isnan(t):
+        return _I32_MAX                  # a > nan is never true
+    if math.isinf(t):
+        return _I32_MAX if t > 0 else _I32_MIN
+    return max(_I32_MIN, min(_I32_MAX, math.floor(t)))
 
 
 def out_stride_for(max_len: int, min_bit_frames: int) -> int:
@@ -72,7 +98,7 @@ def demod_host_arrays(arrays, bit_frames, amp_end_threshold: int = 14000) -> Hos
     ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in keep])
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
     _native.check(_native.lib().afsk_demod_streams_host(
-        ptrs, p(lens, C.c_int32), p(bf, C.c_int32), int(amp_end_threshold), n,
+        ptrs, p(lens, C.c_int32), p(bf, C.c_int32), threshold_lt(amp_end_threshold), n,
         p(res.bytes, C.c_uint8), stride, p(res.nbytes, C.c_int32), p(res.nbits, C.c_int32),
         p(res.clock_idx, C.c_int32), p(res.term_frame, C.c_int32), p(res.status, C.c_int32)))
     return res
@@ -99,7 +125,7 @@ def demod_host_flat(flat, stream_offset, stream_len, bit_frames,
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
     _native.check(_native.lib().afsk_demod_batch_host(
         p(flat, C.c_int16), total, p(offs, C.c_int64), p(lens, C.c_int32), p(bf, C.c_int32),
-        int(amp_end_threshold), n, p(res.bytes, C.c_uint8), stride, p(res.nbytes, C.c_int32),
+        threshold_lt(amp_end_threshold), n, p(res.bytes, C.c_uint8), stride, p(res.nbytes, C.c_int32),
         p(res.nbits, C.c_int32), p(res.clock_idx, C.c_int32), p(res.term_frame, C.c_int32),
         p(res.status, C.c_int32)))
     return res
@@ -238,7 +264,7 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
             out.margins = torch.zeros((n, int(margin_stride)), dtype=torch.int32, device=dev)
         _native.check(_native.lib().afsk_demod_batch_ex(
             samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
-            int(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
             out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
             out.status.data_ptr(), out.corrected.data_ptr(), out.margins.data_ptr(),
             int(out.margins.shape[1]), _stream_ptr(stream)))
@@ -246,7 +272,7 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         return out
     _native.check(_native.lib().afsk_demod_batch(
         samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
-        int(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+        threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
         out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
         out.status.data_ptr(), _stream_ptr(stream)))
     # keep the bit_frames tensor alive until the launch has been enqueued on the stream
@@ -295,7 +321,7 @@ def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
                      i32(n, max(max_blocks, 1)))
     _native.check(_native.lib().afsk_gate_batch(
         samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
-        int(amp_start_threshold), int(amp_end_threshold), n, int(max_bursts),
+        threshold_gt(amp_start_threshold), threshold_lt(amp_end_threshold), n, int(max_bursts),
         res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
         res.burst_len.data_ptr(), res.open_end.data_ptr(), _stream_ptr(stream)))
     return res

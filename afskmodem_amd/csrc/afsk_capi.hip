@@ -74,6 +74,16 @@ public:
                 if (g_scratch.ptr) (void)hipFree(g_scratch.ptr);
                 g_scratch.ptr = nullptr;
                 g_scratch.cap = 0;
+                if (g_scratch.device != dev) {
+                    // events belong to the device they were created on: a cache that moves to
+                    // another device drops them (staging() recreates them there); the pinned
+                    // windows are hipHostMallocPortable and stay
+                    for (int k = 0; k < 2; k++)
+                        if (g_scratch.stage_free[k]) {
+                            (void)hipEventDestroy(g_scratch.stage_free[k]);
+                            g_scratch.stage_free[k] = nullptr;
+                        }
+                }
                 const size_t want = (bytes + (bytes >> 3) + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
                 e = hipMalloc((void**)&g_scratch.ptr, want);
                 if (e != hipSuccess) { g_scratch.ptr = nullptr; return e; }
@@ -92,7 +102,7 @@ public:
     hipError_t staging(char** s0, char** s1, hipEvent_t* e0, hipEvent_t* e1) {
         for (int k = 0; k < 2; k++) {
             if (!g_scratch.stage[k]) {
-                hipError_t e = hipHostMalloc((void**)&g_scratch.stage[k], kStageBytes, hipHostMallocDefault);
+                hipError_t e = hipHostMalloc((void**)&g_scratch.stage[k], kStageBytes, hipHostMallocPortable);
                 if (e != hipSuccess) { g_scratch.stage[k] = nullptr; return e; }
             }
             if (!g_scratch.stage_free[k]) {
@@ -108,6 +118,31 @@ private:
     bool locked_ = false;
     char* private_ptr_ = nullptr;
 };
+
+// The host-buffer entries run on a private NON-BLOCKING stream (one per calling thread and
+// device, created on first use): on the NULL stream every call would synchronise implicitly with
+// all other streams of the process -- the caller's own streams and other threads' calls.
+struct ThreadStream {
+    hipStream_t s = nullptr;
+    int device = -1;
+    ~ThreadStream() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+    hipError_t get(hipStream_t* out) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (s && device != dev) { (void)hipStreamDestroy(s); s = nullptr; }
+        if (!s) {
+            e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e != hipSuccess) { s = nullptr; return e; }
+            device = dev;
+        }
+        *out = s;
+        return hipSuccess;
+    }
+};
+thread_local ThreadStream g_thread_stream;
 
 struct CopyJob { char* dst; const char* src; size_t bytes; };
 
@@ -261,9 +296,9 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
         const int bf = bit_frames[s];
         if (bf < 4 || (bf & 3) || 2 * bf >= AFSK_SYNC_WINDOW)
             return fail(AFSK_E_INVALID_BAUD, "bit_frames must be a multiple of 4 with 2*bf < 4096");
-        if (stream_len[s] < 0 || stream_offset[s] < 0 ||
+        if (stream_len[s] < 0 || stream_len[s] >= (1 << 30) || stream_offset[s] < 0 ||
             stream_offset[s] + stream_len[s] > total_samples)
-            return fail(AFSK_E_INVALID_ARG, "stream outside the sample buffer");
+            return fail(AFSK_E_INVALID_ARG, "stream outside the sample buffer (or 2^30 samples and longer)");
     }
     if (int rc0 = require_device()) return rc0;
 
@@ -278,6 +313,10 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
     const size_t out_bytes_total = n * 20 + bytes_out;
     const size_t total = o_out + out_bytes_total;
     hipStream_t stream = nullptr;
+    {
+        hipError_t e = g_thread_stream.get(&stream);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
+    }
     ScratchLease lease;
     char* d_all = nullptr;
     // host staging: one H2D for the three index arrays, one D2H for all six outputs
@@ -313,6 +352,8 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
     std::memcpy(out_status, h_out.data() + n * 16, n * 4);
     if (bytes_out > 0) std::memcpy(out_bytes, h_out.data() + n * 20, bytes_out);
 done:
+    // nothing may still use the scratch or the staging vectors when they are released
+    if (rc != AFSK_OK) (void)hipStreamSynchronize(stream);
     return rc;   // the lease returns (or frees) the device scratch
 }
 
@@ -379,6 +420,10 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
     const size_t o_out = o_meta + n * 16;
     const size_t out_bytes_total = n * 20 + bytes_out;
     hipStream_t stream = nullptr;
+    {
+        hipError_t e = g_thread_stream.get(&stream);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
+    }
     ScratchLease lease;
     char* d_all = nullptr;
     char* stage[2];

@@ -310,9 +310,10 @@ class Receiver:
         ln = C.c_int32(len(frames))
         bf = C.c_int32(self.__bit_frames)
         L = _native.lib()
+        from . import batch
         _native.check(L.afsk_demod_batch_host(
             frames.ctypes.data_as(C.POINTER(C.c_int16)), len(frames), C.byref(off), C.byref(ln),
-            C.byref(bf), int(self.__amp_end_threshold), 1,
+            C.byref(bf), batch.threshold_lt(self.__amp_end_threshold), 1,
             out_bytes.ctypes.data_as(C.POINTER(C.c_uint8)), cap,
             C.byref(i32[0]), C.byref(i32[1]), C.byref(i32[2]), C.byref(i32[3]), C.byref(i32[4])))
         nbytes, nbits, clock_idx, term_frame, status = (v.value for v in i32)

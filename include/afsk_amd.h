@@ -115,6 +115,10 @@ int afsk_demod_batch_ex(const int16_t *samples, const int64_t *stream_offset,
  * Same operation on HOST buffers: allocates device scratch, copies in, runs the
  * HIP kernel, copies out, synchronises.  This is the PCIe-inclusive convenience
  * path a single Receiver.load() uses; it is not the benchmarked entry.
+ * Both host entries work on a private NON-BLOCKING HIP stream of the calling thread (never the
+ * NULL stream): they do not synchronise with the caller's own streams or with calls made by
+ * other threads, and may be called concurrently (the reference's Receivers are independent
+ * objects, afskmodem.py:275-284).  stream_len[s] must be < 2^30 here as well.
  */
 int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           const int64_t *stream_offset, const int32_t *stream_len,

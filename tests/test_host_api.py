@@ -282,3 +282,22 @@ def test_wav_ingest_is_header_agnostic_like_the_reference(golden, tmp_path):
         assert len(got) == c["n_frames_ref"], c["name"]
         assert sha_i16(got) == c["frames_sha256"], c["name"]
         assert afskmodem.SoundInput.loadFromFile(fn) == got.tolist()
+
+
+def test_float_thresholds_round_like_the_reference_comparison():
+    """ref:375 / :316 compare an INTEGER amplitude with whatever number the user passed
+    (`int(sum/len) < amp_end_threshold`), ref:306 with `>`: the int32 handed to the kernels must
+    give the same truth value for every integer amplitude -- ceil for `<`, floor for `>`."""
+    import random
+    from afskmodem_amd.batch import threshold_gt, threshold_lt
+    rng = random.Random(3)
+    cases = [14000, 14000.0, 14000.5, 13999.999, -0.5, 0.25, 32768.75, float("inf"), float("-inf"),
+             float("nan"), 1e12, -1e12] + [rng.uniform(-5, 40000) for _ in range(200)]
+    for t in cases:
+        T_lt, T_gt = threshold_lt(t), threshold_gt(t)
+        assert isinstance(T_lt, int) and -2 ** 31 <= T_lt < 2 ** 31
+        assert isinstance(T_gt, int) and -2 ** 31 <= T_gt < 2 ** 31
+        base = 0 if t != t or abs(t) > 1e9 else int(t)
+        for a in list(range(base - 3, base + 4)) + [0, 1, 13999, 14000, 14001, 32768]:
+            assert (a < T_lt) == (a < t), (a, t, T_lt)
+            assert (a > T_gt) == (a > t), (a, t, T_gt)
