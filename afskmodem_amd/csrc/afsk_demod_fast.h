@@ -1,5 +1,10 @@
-// afsk_demod_fast.h -- stream-aligned single-pass path for the common baud rates
-// (bit_frames 20 / 40 / 80 / 160 = 2400 / 1200 / 600 / 300 baud).  Included by afsk_demod_impl.h.
+// afsk_demod_fast.h -- stream-aligned single-pass path.  Included by afsk_demod_impl.h.
+// Covers every bit_frames value of the reference's documented 300 - 12000 baud range:
+//   20 / 40 / 80 / 160   (2400 / 1200 / 600 / 300 baud)        fast_rounds: 5 KiB rounds, 80-byte lane pieces
+//   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks, several
+//                                                              symbols per lane
+//   60 / 96 / 100 / 120  (800 / 500 / 480 / 400 baud)          wm_rounds: rounds of any size, watermark refill
+// (anything else -- below 300 baud except 300 itself -- takes the two-pass path of afsk_demod_impl.h).
 //
 // Every sample is fetched from HBM exactly once: the wave starts a 16 KiB LDS-DMA
 // ring at sample 0 the moment it starts, BEFORE the clock index is known, so the
@@ -10,7 +15,7 @@
 //             a descriptor over the whole stream (tail reads return 0).  All 16 chunks
 //             are requested at once, before anything else.
 //   phase A   ref:322-339 once chunks 0..7 have landed: lane-wise sliding correlation
-//             (recover_clock_index_lanes / _lane_steps): every lane keeps the raw samples of
+//             (recover_clock_index_lanes for bit_frames <= 120, _lane_steps for 160): every lane keeps the raw samples of
 //             its own run of consecutive sync offsets in registers and slides the SAD with 7
 //             v_dot2c_i32_i16 per offset.  The first design (a DPP prefix-sum producer feeding
 //             a circular LDS window, 7 lookups per offset: recover_clock_index_fast) is kept
@@ -110,8 +115,12 @@ constexpr int kWinExtraBytes = 2560;                           // own-LDS window
 static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
               "window LDS too small");
 constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave with the prefix window (FLAGS & 8)
-constexpr int kBitBufBytes = 512;                              // phase C's 64-word bit buffer behind the ring
-constexpr int kFastWaveLdsProduct = kRingBytes + kBitBufBytes; // 16.5 KiB per wave: what the product build needs
+constexpr int kMirrorBytes = 256;                              // copy of ring bytes 0..255 right behind the ring: a lane's
+                                                               // piece may run linearly past the ring end (wm_rounds)
+constexpr int kBitBufOffset = kRingBytes + kMirrorBytes;       // phase C's 64-word bit buffer behind the mirror
+constexpr int kBitBufBytes = 512;
+constexpr int kFastWaveLdsProduct = kBitBufOffset + kBitBufBytes;   // 16.75 KiB per wave: what the product build needs
+static_assert(kBitBufOffset + kBitBufBytes <= kFastWaveLds, "bit buffer outside the diagnostic build's LDS");
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
@@ -246,10 +255,10 @@ __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* p
     return (int)__builtin_amdgcn_readfirstlane(cand);
 }
 
-// ---- phase A, lane-wise form (bit_frames 20 / 40) ----------------------------------------
+// ---- phase A, lane-wise form (every single-pass bit_frames up to 120) --------------------
 // Every lane owns GC = 72 CONSECUTIVE sync offsets and the GC + 2*BF raw samples they touch,
-// loaded once from the ring into registers (19 / 14 ds_read_b128; the 144-byte lane stride
-// makes them bank-conflict free).  Against the full-scale square template no abs is needed:
+// loaded once from the ring into registers (14 / 19 / 29 ... 39 ds_read_b128 at bit_frames
+// 20 / 40 / 80 ... 120; the 144-byte lane stride makes them bank-conflict free).  Against the full-scale square template no abs is needed:
 //   total(i) = 65535*BF + sum_j sigma_j * x[i+j],  sigma_j = -1 where the template is 32767,
 //                                                            +1 where it is -32768,
 // so the first offset of a lane is N/2 v_dot2 and every further offset slides by
@@ -970,6 +979,169 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
     }
 }
 
+// ---- bit_frames 60 / 96 / 100 / 120 (800 / 500 / 480 / 400 baud) on the single-pass ring ----
+// Their symbols do not tile a round of whole 1 KiB chunks, so a round is 64 lane pieces of PB bytes
+// (any multiple of 4) and the refill follows a consumed-byte WATERMARK: after the reads of a round
+// every chunk that lies wholly below the next round's first byte is requested again, and the wait
+// before a round is for the chunk holding its last byte (a wave-uniform count -> s_waitcnt through a
+// scalar switch).  A lane reads its piece LINEARLY from (ring offset of its first byte) -- the one
+// piece that straddles the ring end runs on into the 256-byte mirror of ring bytes 0..255 that the
+// wave refreshes (one ds_read_b128 + ds_write_b128 by 16 lanes) in exactly the rounds that cross the
+// end -- so adjacent 4- and 8-byte reads merge into ds_read2_b32 / ds_read2_b64.
+//   bit_frames  60: one lane per symbol, 120-byte pieces (8-byte aligned), per-dword templates
+//               96: two lanes per symbol, 96-byte pieces (six ds_read_b128), quarter sums
+//              100: two lanes per symbol, 100-byte pieces (4-byte aligned), the quarter boundary
+//                   falls inside a dword: mark SAD against a per-dword template + one "hi" SAD
+//              120: two lanes per symbol, 120-byte pieces (8-byte aligned), quarter sums
+template <int BF>
+struct WmGeom {
+    static constexpr bool valid = BF == 60 || BF == 96 || BF == 100 || BF == 120;
+    static constexpr int LPS = BF >= 96 ? 2 : 1;                  // lanes per symbol
+    static constexpr int PL = BF / LPS;                           // samples per lane piece
+    static constexpr int PB = 2 * PL;                             // bytes per piece
+    static constexpr int NO = PL / 2;                             // dwords per piece
+    static constexpr int RW = PB % 16 == 0 ? 16 : (PB % 8 == 0 ? 8 : 4);   // natural alignment of a piece
+    static constexpr int SPP = 64 / LPS;                          // symbols per round = per rxd pass
+    static constexpr int RBYTES = 64 * PB;                        // bytes per round
+    static_assert(!valid || (BF % 4 == 0 && PL % 2 == 0 && PB + 16 <= kMirrorBytes &&
+                             RBYTES + 16 + 1023 < kRingBytes && (LPS == 1 || (BF / 2) % 2 == 0)),
+                  "round geometry");
+};
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {          // n is wave-uniform
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;    case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;    case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;    case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;    case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;    case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;  case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;  case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        default: if (n < 0) wait_vmcnt<0>(); else wait_vmcnt<15>(); break;
+    }
+}
+
+template <int BF, int FLAGS, bool ALIGNED>
+__device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
+                                          uint32_t amp_thr, RxDeferred& rd,
+                                          unsigned long long* words, uint8_t* out_row,
+                                          int out_stride, int32_t* margins, int32_t mstride) {
+    using G = WmGeom<BF>;
+    constexpr int LPS = G::LPS, PL = G::PL, PB = G::PB, NO = G::NO, RW = G::RW, SPP = G::SPP, RBYTES = G::RBYTES;
+    constexpr int Q = BF / 4, H = BF / 2;
+    constexpr uint32_t FULL = 65535u;
+    constexpr int EXTRA = ALIGNED ? 0 : RW;                       // the re-aligning path reads one unit more
+    constexpr int NW = NO + EXTRA / 4;                            // dwords a lane reads
+    typedef u32x4 u32x4_a16 __attribute__((aligned(16)));
+    typedef u32x2 u32x2_a8 __attribute__((aligned(8)));
+    const int lane = fr.lane;
+    const int part = lane & (LPS - 1);
+    const int32_t mlim = K < mstride ? K : mstride;
+    int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
+    for (int r = 0; r < NR; r++, pos += RBYTES) {
+        const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
+        wait_vmcnt_dyn(fr.next - 1 - (last >> 10));               // chunks through last >> 10 have landed
+        const int rb = pos & (kRingBytes - 1);                    // wave-uniform
+        if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
+            if (lane < kMirrorBytes / 16)
+                *reinterpret_cast<u32x4*>(fr.ring + kRingBytes + 16 * lane) =
+                    *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
+            wave_lds_sync();
+        }
+        const uint8_t* src = fr.ring + ((rb + PB * lane) & (kRingBytes - 1));
+        uint32_t W[NW];
+#pragma unroll
+        for (int j = 0; j < NW * 4 / RW; j++) {
+            if constexpr (RW == 16) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4_a16*>(src + 16 * j);
+                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+            } else if constexpr (RW == 8) {
+                const u32x2 t2 = *reinterpret_cast<const u32x2_a8*>(src + 8 * j);
+                W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
+            } else {
+                W[j] = *reinterpret_cast<const uint32_t*>(src + 4 * j);
+            }
+        }
+        uint32_t x[NO];
+        if constexpr (ALIGNED) {
+#pragma unroll
+            for (int d = 0; d < NO; d++) x[d] = W[d];
+        } else {
+            switch (byte0 & (RW - 1)) {                           // wave-uniform, even, non-zero
+                case 2: realign_n<2, NW, NO>(W, x); break;
+                case 4: if constexpr (RW >= 8) realign_n<4, NW, NO>(W, x); break;
+                case 6: if constexpr (RW >= 8) realign_n<6, NW, NO>(W, x); break;
+                case 8: if constexpr (RW == 16) realign_n<8, NW, NO>(W, x); break;
+                case 10: if constexpr (RW == 16) realign_n<10, NW, NO>(W, x); break;
+                case 12: if constexpr (RW == 16) realign_n<12, NW, NO>(W, x); break;
+                default: if constexpr (RW == 16) realign_n<14, NW, NO>(W, x); break;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
+        {   // every chunk wholly below the next round's first byte is free
+            const int lim = ((pos + RBYTES) >> 10) + kRingChunks;
+            while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
+        }
+
+        const int k0 = r * SPP;
+        uint32_t mark = 0, space = 0;
+        if constexpr (LPS == 1) {                                 // whole symbol in the lane: per-dword templates
+#pragma unroll
+            for (int d = 0; d < NO; d++) {
+                const uint32_t lim = limit_pair_biased(x[d]);                              // ref:344
+                const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
+                const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
+                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);                          // ref:346
+                space = __builtin_amdgcn_sad_u16(lim, ts, space);                        // ref:347
+            }
+        } else if constexpr (Q % 2 == 0) {
+            // half a symbol in the lane = quarters (hi, lo) of the mark tone (ref:80-85), all hi (part 0)
+            // or all lo (part 1) of the space tone (ref:68-77); SAD against lo = 65535 * n - SAD against hi
+            uint32_t ha = 0, hb = 0;
+#pragma unroll
+            for (int d = 0; d < Q / 2; d++) ha = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, ha);
+#pragma unroll
+            for (int d = Q / 2; d < Q; d++) hb = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, hb);
+            mark = ha + (FULL * Q - hb);
+            space = part == 0 ? ha + hb : 2u * FULL * Q - ha - hb;
+        } else {
+            // odd quarter length: sample Q - 1 | Q share a dword, so the mark SAD uses per-dword
+            // templates; the space SAD follows from the SAD against "hi" of the whole piece
+            uint32_t mk = 0, th = 0;
+#pragma unroll
+            for (int d = 0; d < NO; d++) {
+                const uint32_t lim = limit_pair_biased(x[d]);
+                const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);   // phases < H: hi Q, lo Q
+                mk = __builtin_amdgcn_sad_u16(lim, tm, mk);
+                th = __builtin_amdgcn_sad_u16(lim, 0xFFFFFFFFu, th);
+            }
+            mark = mk;
+            space = part == 0 ? th : FULL * PL - th;
+        }
+        if constexpr (LPS == 2) {
+            mark = quad_sum<2>(mark);
+            space = quad_sum<2>(space);
+        }
+        const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+        const bool bit = md < sd;                                                        // ref:348-351
+        if (margins && part == 0 && k0 + lane / LPS < mlim) margins[k0 + lane / LPS] = (int32_t)sd - (int32_t)md;
+        const int nv = (K - k0) < SPP ? (K - k0) : SPP;
+        uint64_t bmask = __ballot(bit);
+        if constexpr (LPS == 2) bmask = compress_bits<2>(bmask);
+        rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
+            uint32_t amp = 0;
+#pragma unroll
+            for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);   // ref:94-98
+            if constexpr (LPS == 2) amp = quad_sum<2>(amp);
+            uint64_t am = __ballot(amp >= amp_thr);
+            if constexpr (LPS == 2) am = compress_bits<2>(am);
+            return am;
+        });
+        if (rd.st.phase == 2) break;
+    }
+}
+
 template <int BF, int FLAGS>
 __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
                                                   uint8_t* lds, int lane, RxState& st,
@@ -978,15 +1150,16 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   unsigned long long* stamps = nullptr,
                                                   int32_t* margins = nullptr, int32_t mstride = 0) {
     constexpr bool MULTI = MultiGeom<BF>::valid;
-    constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : 2560 / BF;   // symbols per round
+    constexpr bool WM = WmGeom<BF>::valid;
+    constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : 2560 / BF);   // symbols per round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
     fr.lane = lane;
     // the lane-wise clock recovery needs no LDS of its own: the whole ring is requested at once
     // (the prefix-window form of kbench's FLAGS & 8 keeps its window in ring slots 12..15 for BF > 64)
-    constexpr bool OLD_SYNC = (FLAGS & 8) && !MULTI;
-    constexpr int PRE = OLD_SYNC ? SyncGeom<MULTI ? 40 : BF>::SYNC_CHUNKS : kRingChunks;
+    constexpr bool OLD_SYNC = (FLAGS & 8) && !MULTI && !WM;
+    constexpr int PRE = OLD_SYNC ? SyncGeom<(MULTI || WM) ? 40 : BF>::SYNC_CHUNKS : kRingChunks;
 #pragma unroll
     for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
     fr.next = PRE;
@@ -995,7 +1168,10 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     if constexpr (FLAGS & 1) {
         wait_vmcnt<PRE - 8>();
     } else {
-        if constexpr (BF <= 80 && !OLD_SYNC)
+        // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
+        // not: 72 + 320 samples), sub-windows in steps otherwise
+        constexpr bool LANES_FORM = BF <= 120;
+        if constexpr (LANES_FORM && !OLD_SYNC)
             ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else if constexpr (!OLD_SYNC)
             ci = recover_clock_index_lane_steps<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
@@ -1023,10 +1199,13 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     }
     // phase C state; its bit buffer reuses the LDS behind the ring (phase A's window is done)
     constexpr int PS = SPR < 64 ? SPR : 64;                      // symbols per rxd pass
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kRingBytes);
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
-    if constexpr (MULTI) {
+    if constexpr (WM) {
+        if ((byte0 & (WmGeom<BF>::RW - 1)) == 0) wm_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+        else wm_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    } else if constexpr (MULTI) {
         if ((byte0 & (MultiGeom<BF>::RW - 1)) == 0) multi_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
         else multi_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     } else {

@@ -9,12 +9,13 @@
 // of ref:94-98, Hamming(7,4) decode ref:145-163 and MSB-first byte pack ref:393-399.
 //
 // Two implementations share this file's helpers:
-//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for bit_frames 20 / 40 / 80 / 160
-//     (2400 / 1200 / 600 / 300 baud); every sample is fetched from HBM exactly once.
+//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for every bit_frames of the
+//     reference's documented 300 - 12000 baud range (4 ... 64, 60, 80, 96, 100, 120, 160; the list
+//     is the switch in process_stream); every sample is fetched from HBM exactly once.
 //   * the two-pass path below (recover_clock_index + demod_symbols*): a full 4096-entry prefix
-//     array for phase A, then a clock-index-aligned ring; used for every other valid
-//     bit_frames (demod_symbols_generic) and, with FAST = false, as the round-1 v1 kernel of
-//     the common bauds in kbench A/B runs.
+//     array for phase A, then a clock-index-aligned ring; used for the remaining valid
+//     bit_frames (below 300 baud: demod_symbols_generic) and, with FAST = false, as the round-1
+//     v1 kernel of the common bauds in kbench A/B runs.
 //
 // No MFMA: this is an HBM-bound streaming reduction (2 B read per sample).
 // No workgroup barrier: the 4 waves of a block are independent streams.
@@ -61,7 +62,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
-// floor(total / n) for total < 2^27, n < 2^13, exactly (float estimate + fix-up).
+// floor(total / n) exactly (float estimate + one fix-up step) while the quotient stays below
+// 2^16, i.e. total <= 65535 * n -- true for every SAD total here (n <= 4094 samples of at most
+// 65535 each), although the totals themselves reach ~2^28.
 __device__ __forceinline__ uint32_t div_exact(uint32_t total, uint32_t n, float rcp_n) {
     uint32_t q = (uint32_t)((float)total * rcp_n);
     int32_t r = (int32_t)(total - q * n);
@@ -507,12 +510,13 @@ namespace afsk {
 
 // FLAGS are diagnostic only (tools/kbench.hip); the product instantiates FLAGS = 0.
 constexpr int kFlagSkipSync = 1;    // force clock index 0, no phase A (results wrong unless ci == 0)
-constexpr int kFlagSkipValu = 2;
-constexpr int kFlagOldSync = 8;     // bit_frames 20 / 40: prefix-window clock recovery instead of the lane-wise one
-constexpr int kFlagNoNt = 4;        // default cache policy instead of non-temporal (nt) ring DMA loads    // phase B streams the ring but skips the per-sample VALU work
+constexpr int kFlagSkipValu = 2;    // phase B streams the ring but skips the per-sample VALU work
+constexpr int kFlagNoNt = 4;        // default cache policy instead of non-temporal (nt) ring DMA loads
+constexpr int kFlagOldSync = 8;     // bit_frames 20 / 40 / 80 / 160: prefix-window clock recovery instead of the lane-wise one
+// (FLAGS & 64: per-wave s_memrealtime stamps into DemodArgs::debug_stamps)
 
-// FAST = use the stream-aligned single-pass path (afsk_demod_fast.h) for bit_frames 20/40/160;
-// every other valid bit_frames value takes the two-pass path.
+// FAST = use the stream-aligned single-pass path (afsk_demod_fast.h) for every bit_frames it
+// covers (the switch in process_stream); the remaining valid values take the two-pass path.
 template <int FLAGS, bool FAST>
 struct KernelCfg {
     static constexpr int kLdsPerWave = FAST ? ((FLAGS & 8) ? kFastWaveLds : kFastWaveLdsProduct) : kWaveLds;
@@ -554,6 +558,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
 #define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             AFSK_FAST_CASE(4) AFSK_FAST_CASE(8) AFSK_FAST_CASE(12) AFSK_FAST_CASE(16)
             AFSK_FAST_CASE(24) AFSK_FAST_CASE(32) AFSK_FAST_CASE(48) AFSK_FAST_CASE(64)
+            AFSK_FAST_CASE(60) AFSK_FAST_CASE(96) AFSK_FAST_CASE(100) AFSK_FAST_CASE(120)
 #undef AFSK_FAST_CASE
             case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
             case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;

@@ -122,6 +122,67 @@ def test_gather_host_entry_large_batch_crosses_staging_windows(torch_cuda):
     assert got.status[17] == _native.ST_TOO_SHORT and int((got.status == 0).sum()) >= 890
 
 
+def test_host_entries_from_concurrent_threads(golden, torch_cuda):
+    """The host entries run on a private non-blocking stream per calling thread: several threads
+    calling them at once (independent Receivers, as in the reference, ref:275-284), while the main
+    thread keeps the device busy on torch's stream, all get the results of a lone call."""
+    import threading
+    torch = torch_cuda
+    cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]
+    xs = [build_input(c) for c in cases]
+    bf = [48000 // c["baud"] for c in cases]
+    want = batch.demod_host_arrays(xs, bf)
+    errors = []
+
+    def worker(tid):
+        try:
+            r = afskmodem.Receiver(1200)
+            one = next(i for i, c in enumerate(cases) if c["baud"] == 1200 and c["nbits"] > 0)
+            for it in range(12):
+                sub = slice(tid % 3, len(xs) - (it % 4))
+                got = (batch.demod_host_arrays(xs[sub], bf[sub]) if it % 2 == 0 else
+                       batch.demod_host_flat(np.concatenate(xs[sub]),
+                                             np.concatenate([[0], np.cumsum([len(x) for x in xs[sub]][:-1])]),
+                                             [len(x) for x in xs[sub]], bf[sub]))
+                for f in FIELDS:
+                    assert np.array_equal(getattr(got, f), getattr(want, f)[sub]), (tid, it, f)
+                assert got.payloads() == want.payloads()[sub], (tid, it)
+                assert r.decode_frames(xs[one], string=False).hex() == cases[one]["bytes_hex"]
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    busy = torch.zeros(1 << 24, device="cuda:0")
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    while any(t.is_alive() for t in threads):
+        busy.add_(1.0)                      # work on the caller's own stream in the meantime
+        torch.cuda.synchronize()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_float_squelch_threshold_matches_ceil(torch_cuda):
+    """ref:375 compares int(mean |x|) with the user's number: a float threshold t behaves like
+    ceil(t).  A stream whose tail amplitude is exactly 14000 stops with t = 14000.5, not with 14000."""
+    n, bf_v = 3, 40
+    x = O.get_frames(b"threshold", 1200)[:-4800]
+    tail = np.tile(np.array([14000, -14000], np.int16), 2400)      # mean |x| == 14000 per symbol
+    frames = np.concatenate([x, tail, np.zeros(800, np.int16)])
+    for thr, as_int in ((14000, 14000), (14000.5, 14001), (13999.2, 14000), (14001.0, 14001)):
+        got = batch.demod_host_flat(frames, [0], [len(frames)], bf_v, thr)
+        want = O.demod_batch(frames, np.zeros(1, np.int64), np.array([len(frames)], np.int32),
+                             np.array([bf_v], np.int32), as_int, out_stride=got.bytes.shape[1])
+        assert int(got.nbits[0]) == int(want["nbits"][0]), thr
+        assert got.payloads()[0] == want["bytes"][0, : want["nbytes"][0]].tobytes(), thr
+    lo = batch.demod_host_flat(frames, [0], [len(frames)], bf_v, 14000)
+    hi = batch.demod_host_flat(frames, [0], [len(frames)], bf_v, 14000.5)
+    assert int(lo.nbits[0]) > int(hi.nbits[0]) == 14 * len(b"threshold")
+    r = afskmodem.Receiver(1200, amp_end_threshold=14000.5)
+    assert r.decode_frames(frames, string=False) == b"threshold"
+
+
 def test_plain_c_caller_decodes_on_the_gpu(torch_cuda, tmp_path):
     """tests/cabi/cabi_smoke.c: a C program (no Python, no torch, no HIP headers) synthesises a
     1200-baud stream, calls afsk_demod_batch_host and afsk_demod_streams_host, checks the bytes."""
@@ -193,7 +254,8 @@ def test_soft_outputs_noise_vs_oracle(torch_cuda):
     margin_stride truncates rows without touching the neighbours."""
     torch = torch_cuda
     for bauds, snrs in (((1200,), [20, 8, 5, 3, 0]), ((2400,), [12, 6, 2]), ((300,), [12, 6, 2]),
-                        ((600, 4000), [10, 4]), ((300, 1200, 2400, 600), [9, 5])):
+                        ((600, 4000), [10, 4]), ((300, 1200, 2400, 600), [9, 5]),
+                        ((800, 500, 480, 400), [12, 6, 3]), ((480,), [9, 4]), ((400, 800), [9, 4])):
         n = 32 * len(snrs)
         b = synth_batch(torch, n, bauds, seed=77 + len(snrs) + bauds[0], snr_db=np.repeat(snrs, 32),
                         payload_len=6 if min(bauds) < 1200 else 30)
@@ -404,8 +466,9 @@ def test_noise_sweep_vs_oracle(torch_cuda):
     ber_ok = [all(got.payloads()[i][:34] == b["payload"][i, :34].tobytes()
                   for i in range(k * 64, k * 64 + 64)) for k in range(len(snrs))]
     assert ber_ok[0] and ber_ok[4]          # 30 dB and 10 dB decode error-free
-    for baud, bf in ((300, 160), (2400, 20), (600, 80)):
-        bb = synth_batch(torch, 96, (baud,), seed=32 + bf, snr_db=np.repeat([12, 6, 2], 32))
+    for baud, bf in ((300, 160), (2400, 20), (600, 80), (800, 60), (500, 96), (480, 100), (400, 120)):
+        bb = synth_batch(torch, 96, (baud,), seed=32 + bf, snr_db=np.repeat([12, 6, 2], 32),
+                         payload_len=None if baud in synth.ONE_SECOND_PAYLOAD else 10)
         st = batch.out_stride_for(bb["total"], bf)
         g = batch.demod_batch(bb["samples"], bb["off"], bb["ln"], bf, 14000, out_stride=st).cpu()
         w = O.demod_batch(bb["samples"].cpu().numpy(), bb["h_off"], bb["h_ln"], bb["h_bf"], 14000,
@@ -573,11 +636,12 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
 def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     """The single-pass kernel re-aligns ring reads by (2*ci) & 15: exercise all 8 shifts, ring
     wrap-around on long streams, and tiny symbol counts, for every baud rate of the single-pass
-    kernel (300 ... 12000 baud)."""
+    kernel (300 ... 12000 baud; for 800 / 500 / 480 / 400 baud also the mirror behind the ring
+    that lets a lane piece run linearly past the ring end)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     pieces, bfs = [], []
-    for baud in (300, 600, 1200, 2400, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750):
+    for baud in (300, 600, 1200, 2400, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400):
         bf = 48000 // baud
         t = afskmodem.Transmitter(baud, 0.1)
         w_short = t.wav_samples(rng.integers(0, 256, 4, dtype=np.uint8).tobytes())
@@ -677,7 +741,7 @@ def test_random_garbage_streams(torch_cuda):
     torch = torch_cuda
     rng = np.random.default_rng(2718)
     pieces, bfs = [], []
-    for bf in (20, 40, 160, 80, 480, 8):
+    for bf in (20, 40, 160, 80, 480, 8, 60, 96, 100, 120):
         for L in (4096, 6000, 20000):
             pieces.append(rng.integers(-32768, 32768, L).astype(np.int16)); bfs.append(bf)
         pieces.append(np.full(9000, -32768, np.int16)); bfs.append(bf)

@@ -20,7 +20,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
 total_bad = 0
-for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 480):
+for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400, 200):
     bf = 48000 // baud
     burst = O.wav_convert(O.get_frames(bytes(rng.integers(0, 256, 3, dtype=np.uint8)), baud, 0.03))
     pieces = []

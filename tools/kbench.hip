@@ -34,11 +34,13 @@ static void launch_geom(const DemodArgs& a, hipStream_t s) {
 // any reuse of the 256 MiB Infinity Cache between back-to-back launches
 static const int16_t* g_copies[4] = {nullptr, nullptr, nullptr, nullptr};
 static int g_rot = 0;
+#ifndef KBENCH_LITE
 static void launch_rotating(const DemodArgs& a, hipStream_t s) {
     DemodArgs b = a;
     b.samples = g_copies[(g_rot++) & 3];
     launch_flags<0, true>(b, s);
 }
+#endif
 
 // the product library's entry point (same kernel, compiled in its own translation unit)
 typedef int (*lib_demod_fn)(const int16_t*, const int64_t*, const int32_t*, const int32_t*, int32_t, int32_t,
@@ -63,7 +65,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 3 ? atoi(argv[3]) : 15;
     const int reps = argc > 4 ? atoi(argv[4]) : 5;
     const int L = 48000, bfv = 48000 / baud;
-    const int plen_v = baud == 1200 ? 34 : (baud == 300 ? 8 : (baud == 600 ? 16 : 68));
+    const int plen_v = (L - 24000 - 4 * bfv - 4800) / (14 * bfv);   // payload bytes of an (at most) 1 s stream
     std::vector<int64_t> off(n); std::vector<int32_t> len(n, L), bf(n, bfv), pl(n, plen_v), ts(n, baud / 4);
     std::vector<uint8_t> payload((size_t)n * plen_v);
     for (size_t i = 0; i < payload.size(); i++) payload[i] = (uint8_t)((i * 2654435761u) >> 13);
@@ -112,19 +114,26 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ob, (size_t)n * stride)); CK(hipMalloc(&d_i32, (size_t)n * 5 * 4));
     DemodArgs a{d_x, d_off, d_len, d_bf, 14000, n, d_ob, stride, d_i32, d_i32 + n, d_i32 + 2 * n, d_i32 + 3 * n, d_i32 + 4 * n};
 
+    // -DKBENCH_LITE: only the two-pass kernel is compiled in (seconds instead of minutes); the
+    // single-pass kernel is timed through the library entries (libafsk_amd.so and KBENCH_LIB_B).
     std::vector<Variant> vs = {
         {"v1 two-pass", launch_flags<0, false>, true},
+#ifndef KBENCH_LITE
         {"v2 fast (nt)", launch_flags<0, true>, true},
+        {"v2 skip_sync", launch_flags<1, true>, true},
+        {"v2 skip_valu", launch_flags<2, true>, false},
+        {"v2 skip_sync+valu", launch_flags<3, true>, false},
+#endif
+#ifdef KBENCH_FULL
         {"v2 prefix-window sync", launch_flags<8, true>, true},
         {"v2 fast default-policy", launch_flags<4, true>, true},
         {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
         {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},
-        {"wpb3 lds16.5K (9/CU)", launch_geom<3, 16896>, true},
-        {"wpb1 lds16.5K (9/CU)", launch_geom<1, 16896>, true},
-        {"v2 skip_sync", launch_flags<1, true>, true},
-        {"v2 skip_valu", launch_flags<2, true>, false},
-        {"v2 skip_sync+valu", launch_flags<3, true>, false},
+        {"wpb3 lds17K (9/CU)", launch_geom<3, 17408>, true},
+        {"wpb1 lds17K (9/CU)", launch_geom<1, 17408>, true},
+#endif
     };
+#ifndef KBENCH_LITE
     {   // timeline of one launch of the diagnostic (stamped) build
         unsigned long long* d_st; CK(hipMalloc(&d_st, (size_t)n * 32)); CK(hipMemset(d_st, 0, (size_t)n * 32));
         DemodArgs as = a; as.debug_stamps = d_st;
@@ -156,6 +165,7 @@ int main(int argc, char** argv) {
                pct(3, 1.0), pct(3, 0.4999), pct(0, 0.5001));
         CK(hipFree(d_st));
     }
+#endif
     if (n <= 8192) {
         g_copies[0] = d_x;
         for (int c = 1; c < 4; c++) {
@@ -163,16 +173,18 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(p, d_x, (size_t)n * L * 2, hipMemcpyDeviceToDevice));
             g_copies[c] = p;
         }
+#ifndef KBENCH_LITE
         vs.insert(vs.begin() + 2, Variant{"v2 fast, 4 rotating inputs", launch_rotating, true});
+#endif
     }
     if (void* h = dlopen("../afskmodem_amd/csrc/libafsk_amd.so", RTLD_NOW)) {
         g_lib_demod = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
-        if (g_lib_demod) vs.insert(vs.begin() + 2, Variant{"libafsk_amd.so entry", launch_lib, true});
+        if (g_lib_demod) vs.insert(vs.begin() + 1, Variant{"libafsk_amd.so entry", launch_lib, true});
     }
     if (const char* pb = getenv("KBENCH_LIB_B")) {
         if (void* h = dlopen(pb, RTLD_NOW | RTLD_LOCAL)) {
             g_lib_demod_b = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
-            if (g_lib_demod_b) vs.insert(vs.begin() + 3, Variant{"lib B entry", launch_lib_b, true});
+            if (g_lib_demod_b) vs.insert(vs.begin() + 2, Variant{"lib B entry", launch_lib_b, true});
         } else {
             printf("cannot load %s: %s\n", pb, dlerror());
         }
