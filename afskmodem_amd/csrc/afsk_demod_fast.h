@@ -36,17 +36,6 @@ namespace afsk {
 constexpr int kRingBytes = 16384;
 constexpr int kRingChunks = 16;
 
-// Inclusive wave scan (64 lanes) with DPP: 4 row_shr steps + row_bcast:15 + row_bcast:31.
-__device__ __forceinline__ int32_t wave_incl_scan_dpp(int32_t v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
     uint8_t* ring;                 // wave-uniform LDS base of the 16 KiB ring
@@ -596,6 +585,77 @@ __device__ __forceinline__ void rxd_pass(RxDeferred& d, uint64_t bmask, int nv, 
         rxd_flush<PS>(d, k0 + nv, lane, words, out_row, out_stride);
 }
 
+// One ROUND of SPL x 64 symbols in a single phase-C step (instead of SPL dependent scalar passes):
+// lane p < SPL takes the ballot word of symbols k0 + 64p .. k0 + 64p + 63 (v_cndmask), so the
+// terminator scan (ref:386-390) and the squelch stop (ref:372-376) run on all SPL words at once in
+// 64-bit VALU arithmetic -- the three decisions before a word come from the neighbouring lane by
+// DPP row_shr:1 (lane 0: the carried history) -- and one ds_write_b64 parks all words.  What is
+// left on the scalar unit is "any hit?" (one ballot) and, once per stream each, locating the first
+// terminator / first quiet symbol.  amp_word(p) returns the "loud enough" ballot of slice p and is
+// only evaluated from the round with the terminator on, like the reference (ref:361-366).
+template <int SPL, class AmpFn>
+__device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL], int32_t K, int k0,
+                                          int lane, unsigned long long* words, uint8_t* out_row,
+                                          int out_stride, AmpFn&& amp_word) {
+    static_assert(SPL >= 2 && SPL <= 16, "one DPP row");
+    uint32_t wlo = 0, whi = 0;
+#pragma unroll
+    for (int p = 0; p < SPL; p++) {
+        wlo = lane == p ? (uint32_t)B[p] : wlo;                // v_cndmask with the scalar word as a source
+        whi = lane == p ? (uint32_t)(B[p] >> 32) : whi;
+    }
+    const int rem = K - k0 - 64 * lane;                        // symbols of this lane's word that exist
+    const uint64_t valid = (lane >= SPL || rem <= 0) ? 0ull : (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
+    const uint64_t w = (((uint64_t)whi << 32) | wlo) & valid;
+    if (lane < SPL) words[((k0 >> 6) + lane) & (kBitWords - 1)] = w;
+    d.filled = k0 + 64 * SPL;
+    const int nv = (K - k0) < 64 * SPL ? (K - k0) : 64 * SPL;  // symbols of this round
+    int start = -1;                                            // first data symbol of the round, -1 = none
+    if (d.st.phase == 0) {
+        uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(w >> 32), 0x111, 0xf, 0xf, true);   // row_shr:1
+        if (lane == 0) phi = d.st.hist << 29;                  // decisions k0-3 .. k0-1
+        const uint64_t b3 = (w << 3) | (uint64_t)(phi >> 29);
+        const uint64_t b2 = (w << 2) | (uint64_t)(phi >> 30);
+        const uint64_t b1 = (w << 1) | (uint64_t)(phi >> 31);
+        const uint64_t hit = b3 & ~b2 & ~b1 & ~w & valid;      // window == 1,0,0,0 (ref:386-390)
+        const uint64_t any = __ballot(hit != 0);
+        if (any) {
+            const int p = __builtin_ctzll(any);
+            const uint64_t hw = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hit >> 32), p) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hit, p);
+            start = 64 * p + __builtin_ctzll(hw) + 1;
+            d.st.term_sym = k0 + start;
+            d.st.phase = 1;
+        } else {
+            d.st.hist = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), SPL - 1) >> 29;
+        }
+    } else if (d.st.phase == 1) {
+        start = 0;
+    }
+    if (start >= 0 && start < nv) {                            // squelch stop (ref:372-376)
+        uint32_t alo = 0, ahi = 0;
+#pragma unroll
+        for (int p = 0; p < SPL; p++) {
+            const uint64_t a = amp_word(p);
+            alo = lane == p ? (uint32_t)a : alo;
+            ahi = lane == p ? (uint32_t)(a >> 32) : ahi;
+        }
+        const int rel = start - 64 * lane;                     // data starts at bit rel of this lane's word
+        const uint64_t from = rel <= 0 ? ~0ull : (rel >= 64 ? 0ull : ~((1ull << rel) - 1ull));
+        const uint64_t stop = ~(((uint64_t)ahi << 32) | alo) & valid & from;
+        const uint64_t any = __ballot(stop != 0);
+        if (any) {
+            const int p = __builtin_ctzll(any);
+            const uint64_t sw = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(stop >> 32), p) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)stop, p);
+            d.end_sym = k0 + 64 * p + __builtin_ctzll(sw);
+            d.st.phase = 2;
+        }
+    }
+    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
+        rxd_flush<64>(d, k0 + nv, lane, words, out_row, out_stride);
+}
+
 // end of stream: K symbols were examined unless the squelch stopped earlier
 template <int PS>
 __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, unsigned long long* words,
@@ -704,16 +764,11 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
             if (k0 + lane < mlim) margins[k0 + lane] = (int32_t)sd0 - (int32_t)md0;
             if (k0 + 64 + lane < mlim) margins[k0 + 64 + lane] = (int32_t)sd1 - (int32_t)md1;
         }
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int kk = k0 + 64 * half;
-            if (kk >= K || rd.st.phase == 2) break;
-            const int nv = (K - kk) < 64 ? (K - kk) : 64;
-            rxd_pass<64>(rd, __ballot(bit[half]), nv, kk, lane, words, out_row, out_stride, [&]() {
-                const uint32_t amp = half == 0 ? abs_sum<0, 10>(x) : abs_sum<10, 20>(x);
-                return __ballot(amp >= amp_thr);
-            });
-        }
+        const uint64_t B[2] = {__ballot(bit[0]), __ballot(bit[1])};
+        rxd_round<2>(rd, B, K, k0, lane, words, out_row, out_stride, [&](int half) {
+            const uint32_t amp = half == 0 ? abs_sum<0, 10>(x) : abs_sum<10, 20>(x);
+            return __ballot(amp >= amp_thr);
+        });
     } else {                                  // BF = 80 / 160: two / four lanes per symbol
         static_assert(BF == 80 || BF == 160, "fast path supports bit_frames 20, 40, 80, 160");
         constexpr int LPS = BF / 40;                               // lanes per symbol
@@ -941,10 +996,10 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         fr.next += R;
 
         const int k0 = r * SPR;
+        uint64_t B[SPL];
 #pragma unroll
         for (int piece = 0; piece < SPL; piece++) {
             const int kk = k0 + 64 * piece;
-            if (kk >= K || rd.st.phase == 2) break;
             uint32_t mark = 0, space = 0;
             if constexpr (BF % 8 == 0) {
                 // quarters are whole dwords: SAD against "hi" per quarter gives both correlators
@@ -967,13 +1022,19 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             }
             const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
             if (margins && kk + lane < mlim) margins[kk + lane] = (int32_t)sd - (int32_t)md;
-            const int nv = (K - kk) < 64 ? (K - kk) : 64;
-            rxd_pass<64>(rd, __ballot(md < sd), nv, kk, lane, words, out_row, out_stride, [&]() {
-                uint32_t amp = 0;
+            B[piece] = __ballot(md < sd);                                      // ref:348-351
+        }
+        auto amp_word = [&](int piece) {                                       // ref:94-98, ref:375
+            uint32_t amp = 0;
 #pragma unroll
-                for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[NO * piece + d] ^ kBias, kBias, amp);
-                return __ballot(amp >= amp_thr);
-            });
+            for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[NO * piece + d] ^ kBias, kBias, amp);
+            return __ballot(amp >= amp_thr);
+        };
+        if constexpr (SPL == 1) {
+            const int nv = (K - k0) < 64 ? (K - k0) : 64;
+            rxd_pass<64>(rd, B[0], nv, k0, lane, words, out_row, out_stride, [&]() { return amp_word(0); });
+        } else {
+            rxd_round<SPL>(rd, B, K, k0, lane, words, out_row, out_stride, amp_word);
         }
         if (rd.st.phase == 2) break;
     }

@@ -53,13 +53,30 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
+// Inclusive wave scan (64 lanes) with DPP: 4 row_shr steps + row_bcast:15 + row_bcast:31.
+__device__ __forceinline__ int32_t wave_incl_scan_dpp(int32_t v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
+}
+
+// Minimum over the 64 lanes, returned wave-uniform.  DPP only (row_shr 1/2/4/8 inside the rows of 16,
+// then row_bcast:15 / :31 across rows; lanes without a source keep the identity): six VALU steps and
+// one v_readlane -- __shfl_xor would be six ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    const int id = (int)0xFFFFFFFFu;
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // floor(total / n) exactly (float estimate + one fix-up step) while the quotient stays below
@@ -228,15 +245,7 @@ __device__ __forceinline__ int recover_clock_index(const int16_t* xs, int32_t le
     }
     int32_t incl[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) incl[r] = tot[r];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int32_t t = __shfl_up(incl[r], d, 64);
-            if (lane >= d) incl[r] += t;
-        }
-    }
+    for (int r = 0; r < 8; r++) incl[r] = wave_incl_scan_dpp(tot[r]);
     int32_t carry = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -248,7 +257,7 @@ __device__ __forceinline__ int recover_clock_index(const int16_t* xs, int32_t le
                    (uint32_t)(base + c[r][6]), (uint32_t)(base + c[r][7])};
         *reinterpret_cast<u32x4*>(dst) = a;
         *reinterpret_cast<u32x4*>(dst + 4) = b;
-        carry += __shfl(incl[r], 63, 64);
+        carry += __builtin_amdgcn_readlane(incl[r], 63);
     }
     // Same wave wrote and reads P: LDS ops of one wave complete in order.
     wave_lds_sync();

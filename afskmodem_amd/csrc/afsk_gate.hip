@@ -38,9 +38,16 @@ __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
             acc = __builtin_amdgcn_sad_u16(v[j][k] ^ 0x80008000u, 0x80008000u, acc);   // sum |x|
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
-    if (lane == 0) a.block_amp[(int64_t)s * a.max_blocks + b] = (int32_t)(acc >> 11);    // int(sum/2048)
+    // wave sum with DPP (row_shr 1/2/4/8, row_bcast:15 / :31): lane 63 ends up with the total;
+    // __shfl_xor would be six ds_bpermute round trips
+    int t = (int)acc;
+    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);
+    if (lane == 63) a.block_amp[(int64_t)s * a.max_blocks + b] = (int32_t)((uint32_t)t >> 11);    // int(sum/2048)
 }
 
 __global__ __launch_bounds__(256) void gate_scan_kernel(GateArgs a) {
