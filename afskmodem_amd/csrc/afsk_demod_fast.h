@@ -1069,20 +1069,6 @@ struct WmGeom {
                   "round geometry");
 };
 
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {          // n is wave-uniform
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;    case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;    case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;    case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;    case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;    case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;  case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break;  case 13: wait_vmcnt<13>(); break;
-        case 14: wait_vmcnt<14>(); break;
-        default: if (n < 0) wait_vmcnt<0>(); else wait_vmcnt<15>(); break;
-    }
-}
-
 template <int BF, int FLAGS, bool ALIGNED>
 __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                           uint32_t amp_thr, RxDeferred& rd,

@@ -424,6 +424,20 @@ __device__ __forceinline__ void demod_symbols(const int16_t* xs, int32_t len, in
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {          // n is wave-uniform
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;    case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;    case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;    case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;    case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;    case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;  case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;  case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        default: if (n < 0) wait_vmcnt<0>(); else wait_vmcnt<15>(); break;
+    }
+}
+
 __device__ __forceinline__ void wait_vmcnt_upto8(int n) {
     switch (n) {
         case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;

@@ -16,6 +16,15 @@ TAIL_SILENCE = 4800
 ONE_SECOND_PAYLOAD = {300: 8, 600: 16, 1200: 34, 2400: 68}
 
 
+def one_second_payload(baud: int, training_time: float = 0.5, stream_len: int = SAMPLE_RATE) -> int:
+    """Largest payload (bytes) whose Transmitter frames (ref:452-469: training, terminator, 14
+    symbols per byte, 4800 tail zeros) fit stream_len samples; equals ONE_SECOND_PAYLOAD for the
+    BASELINE bauds."""
+    bf = SAMPLE_RATE // int(baud)
+    room = stream_len - ts_cycles_for(baud, training_time) * 2 * bf - 4 * bf - TAIL_SILENCE
+    return max(room // (14 * bf), 0)
+
+
 def _hash32(x: np.ndarray) -> np.ndarray:
     x = x.astype(np.uint32)
     x ^= x >> np.uint32(16)

@@ -53,6 +53,9 @@ WORKLOADS = {
     "config3": (65536, (300, 1200, 2400), None, "configs[2]: 65536 streams x 1 s mixed baud {300,1200,2400}, clean, per GPU"),
     "config4": (65536, (1200,), 10.0, "configs[3]: 65536 streams x 1 s @1200 baud, additive noise SNR 10 dB, per GPU"),
     "config5": (65536, (1200,), None, "configs[4]: 65536 streams x 1 s @1200 baud, clean, per GPU (524288 on 8)"),
+    # not a BASELINE config: --workload custom --bauds 480,12000 [--streams N] times any baud mix
+    # (profiles of the rates furthest from the roofline)
+    "custom": (4096, (1200,), None, "custom: streams x 1 s, clean, bauds from --bauds, per GPU"),
 }
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
 STREAM_LEN = 48000
@@ -187,8 +190,8 @@ class Shard:
         gidx = np.arange(first, first + n)
         baud_arr = np.asarray([bauds[i % len(bauds)] for i in gidx], np.int32)
         bf_h = (48000 // baud_arr).astype(np.int32)
-        plen_h = np.asarray([synth.ONE_SECOND_PAYLOAD[int(b)] for b in baud_arr], np.int32)
-        pstride = max(synth.ONE_SECOND_PAYLOAD[int(b)] for b in bauds)
+        plen_h = np.asarray([synth.one_second_payload(int(b)) for b in baud_arr], np.int32)
+        pstride = max(synth.one_second_payload(int(b)) for b in bauds)
         payload_h = synth.payload_bytes(PAYLOAD_SEED, first, n, pstride)
         ts_h = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_arr], np.int32)
         return bf_h, plen_h, payload_h, ts_h
@@ -197,8 +200,11 @@ class Shard:
         """(Re)write inputs[0]: Transmitter frames (+ additive noise at snr_db)."""
         from afskmodem_amd import batch, synth
         x = self.inputs[0]
+        # the .wav writer's decimate/duplicate quirk (ref:239-244) is part of every Transmitter.save
+        # stream; at 12000 baud it destroys the mark tone (in the reference too), so a custom
+        # workload with that rate uses the ideal frames
         batch.modulate_batch(self._payload_d, self._plen_d, self.bf, self._ts_d, self.off, self.ln,
-                             STREAM_LEN, x, True)
+                             STREAM_LEN, x, 12000 not in self.bauds)
         if snr_db is not None:
             batch.add_noise_batch(x, self.off, self.ln, STREAM_LEN, synth.snr_to_scale_q24(snr_db),
                                   seed=seed, stream_idx_base=self.first)
@@ -648,6 +654,7 @@ def main() -> None:
     ap.add_argument("--sub-cpu-sample", type=int, default=1024,
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--bauds", default="", help="with --workload custom: comma list of baud rates cycled over the streams")
     ap.add_argument("--preroll-ms", type=float, default=300.0,
                     help="untimed launches of the same kernel before the warm-up steps, so the "
                          "GPU clocks have settled (the first ~20 ms under load run 4-6 %% slower)")
@@ -660,6 +667,9 @@ def main() -> None:
                     help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
     args = ap.parse_args()
 
+    if args.bauds:
+        bl = tuple(int(b) for b in args.bauds.split(","))
+        WORKLOADS["custom"] = (WORKLOADS["custom"][0], bl, None, f"custom: streams x 1 s, clean, bauds {list(bl)}, per GPU")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher.  Nothing above or below this line
         # touches the GPU in this process (device_count() does not initialise it on this image).

@@ -114,6 +114,12 @@ def test_synth_helpers():
     for baud, nb in synth.ONE_SECOND_PAYLOAD.items():
         n = synth.frames_needed(48000 // baud, synth.ts_cycles_for(baud), nb)
         assert n <= 48000 and n == len(O.get_frames(bytes(nb), baud))
+        assert synth.one_second_payload(baud) == nb
+    for baud in (12000, 6000, 4000, 800, 500, 480, 400, 200, 100):      # largest payload that still fits 1 s
+        nb = synth.one_second_payload(baud)
+        bf = 48000 // baud
+        assert synth.frames_needed(bf, synth.ts_cycles_for(baud), nb) <= 48000
+        assert synth.frames_needed(bf, synth.ts_cycles_for(baud), nb + 1) > 48000
     assert synth.snr_to_scale_q24(10) == 2297180 or synth.snr_to_scale_q24(10) > 0
 
 

@@ -5,5 +5,5 @@ cd "$(dirname "$0")"
 export KBENCH_LIB_B=${KBENCH_LIB_B:-$(pwd)/libafsk_r1.so}
 for b in $1; do
   echo "=== baud $b"
-  timeout 300 ./kbench ${2:-4096} $b 12 5 2>&1 | grep -E "base:|outputs|median|HIP error"
+  timeout 300 ./kbench ${2:-4096} $b 12 5 2>&1 | grep -E "base:|!=|median|HIP error"
 done

@@ -51,10 +51,12 @@ static void launch_lib(const DemodArgs& a, hipStream_t s) {
                 a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
 }
 // a second build of the library (KBENCH_LIB_B=<path>): A/B of two source revisions in one process
-static lib_demod_fn g_lib_demod_b = nullptr;
-static void launch_lib_b(const DemodArgs& a, hipStream_t s) {
-    g_lib_demod_b(a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
-                  a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
+// (a colon-separated list loads up to four builds: "lib B entry", "lib C entry", ...)
+static lib_demod_fn g_lib_x[4] = {nullptr, nullptr, nullptr, nullptr};
+template <int I>
+static void launch_lib_x(const DemodArgs& a, hipStream_t s) {
+    g_lib_x[I](a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
+               a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
 }
 
 struct Variant { const char* name; launch_fn fn; bool exact; };
@@ -182,11 +184,23 @@ int main(int argc, char** argv) {
         if (g_lib_demod) vs.insert(vs.begin() + 1, Variant{"libafsk_amd.so entry", launch_lib, true});
     }
     if (const char* pb = getenv("KBENCH_LIB_B")) {
-        if (void* h = dlopen(pb, RTLD_NOW | RTLD_LOCAL)) {
-            g_lib_demod_b = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
-            if (g_lib_demod_b) vs.insert(vs.begin() + 2, Variant{"lib B entry", launch_lib_b, true});
-        } else {
-            printf("cannot load %s: %s\n", pb, dlerror());
+        static const launch_fn tramp[4] = {launch_lib_x<0>, launch_lib_x<1>, launch_lib_x<2>, launch_lib_x<3>};
+        static std::string names[4];
+        std::string list(pb);
+        size_t pos = 0;
+        for (int i = 0; i < 4 && pos <= list.size(); i++) {
+            size_t e = list.find(':', pos);
+            std::string one = list.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+            pos = e == std::string::npos ? list.size() + 1 : e + 1;
+            if (one.empty()) continue;
+            if (void* h = dlopen(one.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+                g_lib_x[i] = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
+                size_t sl = one.rfind('/');
+                names[i] = std::string("lib ") + (char)('B' + i) + " " + (sl == std::string::npos ? one : one.substr(sl + 1));
+                if (g_lib_x[i]) vs.insert(vs.begin() + 2 + i, Variant{names[i].c_str(), tramp[i], true});
+            } else {
+                printf("cannot load %s: %s\n", one.c_str(), dlerror());
+            }
         }
     }
     if (const char* only = getenv("KBENCH_ONLY")) {          // run a single variant (cache-state studies)
@@ -224,7 +238,7 @@ int main(int argc, char** argv) {
     for (size_t v = 0; v < vs.size(); v++) {
         std::sort(times[v].begin(), times[v].end());
         float med = times[v][times[v].size() / 2], mn = times[v][0];
-        printf("%-18s median %8.2f us  min %8.2f us   full-buffer %.2f TB/s (median)\n", vs[v].name, med * 1e3, mn * 1e3, bytes / (med * 1e-3) / 1e12);
+        printf("%-28s median %8.2f us  min %8.2f us   full-buffer %.2f TB/s (median)\n", vs[v].name, med * 1e3, mn * 1e3, bytes / (med * 1e-3) / 1e12);
     }
     return 0;
 }

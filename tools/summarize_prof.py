@@ -50,5 +50,22 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     # exactly half the bytes of a wide (16 B/lane) coalesced streaming read -> double it.
     out["hbm_bytes_per_launch"] = int(2 * out["FETCH_SIZE"]["avg_raw_kib"] * 1024
                                       + out["WRITE_SIZE"]["avg_raw_kib"] * 1024)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_hash: ties the figures to the kernel source they were measured on)
+out["kernel_source_hash"] = bench.kernel_source_hash()
 print(json.dumps(out, indent=1))
 json.dump(out, open(os.path.join(base, f"prof_summary_{wl}.json"), "w"), indent=1)
+# profiles/traffic_latest.json is what bench.py reports as roofline.traffic (with its provenance)
+if "hbm_bytes_per_launch" in out and wl in bench.WORKLOADS and wl != "custom":
+    tf = os.path.join(base, "traffic_latest.json")
+    try:
+        tj = json.load(open(tf))
+    except Exception:  # noqa: BLE001
+        tj = {}
+    if tj.get("kernel_source_hash") != out["kernel_source_hash"]:
+        tj = {"kernel_source_hash": out["kernel_source_hash"], "entries": {}}
+    grid = int(out.get("demod_kernel_resources", {}).get("Grid_Size") or 0)
+    tj["entries"][wl] = {"streams": grid // 64 if grid else bench.WORKLOADS[wl][0],
+                         "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
+                         "source": f"profiles/{os.environ.get('PROF_TAG', 'r2')}_{wl}_summary.json"}
+    json.dump(tj, open(tf, "w"), indent=1)
