@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libafsk_amd.so")
 OK = 0
 E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP, E_HOST = -1, -2, -3, -4, -5
 ST_OK, ST_TOO_SHORT, ST_NO_DATA, ST_INVALID_BAUD = 0, 1, 2, 3
+WAV_OK = 0
 
 SAMPLE_RATE = 48000
 SYNC_WINDOW = 4096
@@ -54,6 +55,9 @@ SIGNATURES = {
     "afsk_demod_streams_host": (C.c_int, [C.POINTER(C.c_void_p), _i32p, _i32p, C.c_int32, C.c_int32,
                                           _u8p, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "afsk_host_scratch_release": (C.c_int, []),
+    "afsk_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p, _i64p, _i32p]),
+    "afsk_wav_upload": (C.c_int, [C.POINTER(C.c_char_p), _i64p, _i64p, _i64p, C.c_int32, C.c_void_p,
+                                  C.c_int64]),
     "afsk_modulate_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p]),

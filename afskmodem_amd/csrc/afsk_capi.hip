@@ -2,6 +2,12 @@
 // Host-side argument checks, error strings and kernel launches; no torch types.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -188,6 +194,161 @@ void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
     if (!parts.empty()) run(parts[0]);
     for (size_t k = spawned; k < parts.size(); k++) run(parts[k]);
     for (auto& x : th) x.join();
+}
+
+// A small persistent pool for the file-ingest entries: spawning 15 threads per staging window cost
+// more than filling the window.  run(n, width, body) executes body(i) for i in [0, n) on up to
+// `width` threads (the caller is one of them) and returns when all are done; one job at a time.
+class IoPool {
+public:
+    ~IoPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    template <class F>
+    void run(size_t n, unsigned width, F&& body) {
+        if (n == 0) return;
+        if (width <= 1 || n == 1) {
+            for (size_t i = 0; i < n; i++) body(i);
+            return;
+        }
+        std::lock_guard<std::mutex> job_lock(job_mu_);        // one job at a time
+        grow(std::min<size_t>(width - 1, n - 1));
+        std::function<void(size_t)> fn = std::ref(body);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_.store(0); busy_ = th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        drain(fn, n);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void drain(const std::function<void(size_t)>& fn, size_t n) {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) return;
+            fn(i);
+        }
+    }
+    void grow(size_t want) {
+        uint64_t gen_now;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            gen_now = gen_;                                     // a new worker starts with the NEXT job
+        }
+        while (th_.size() < want) {
+            try {
+                th_.emplace_back([this, gen_now] { worker(gen_now); });
+            } catch (...) {
+                break;                                          // fewer helpers: the caller drains the rest
+            }
+        }
+    }
+    void worker(uint64_t seen) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
+            if (quit_) return;
+            seen = gen_;
+            const std::function<void(size_t)>* fn = fn_;
+            const size_t n = n_;
+            lk.unlock();
+            if (fn) drain(*fn, n);
+            lk.lock();
+            if (--busy_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> th_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, busy_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    bool quit_ = false;
+};
+IoPool& io_pool() {
+    static IoPool* p = new IoPool();     // never destroyed: no join of parked threads at process exit
+    return *p;
+}
+template <class F>
+void parallel_for(size_t n, unsigned max_threads, F&& body) {
+    io_pool().run(n, max_threads, body);
+}
+
+unsigned io_threads() {
+    static const unsigned v = [] {
+        const char* e = std::getenv("AFSK_IO_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(32u, hw);
+    }();
+    return v;
+}
+
+bool pread_all(int fd, void* dst, size_t bytes, int64_t off) {
+    char* p = (char*)dst;
+    while (bytes > 0) {
+        const ssize_t r = pread(fd, p, bytes, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+
+uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+
+// The chunk walk of Python's wave.Wave_read.initfp + chunk.Chunk (what ref:214 runs), without
+// interpreting the audio format: returns AFSK_WAV_* and the byte range readframes(getnframes()) covers.
+int wav_probe_one(const char* path, int64_t* data_off, int64_t* data_bytes) {
+    *data_off = 0; *data_bytes = 0;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return AFSK_WAV_IO;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return AFSK_WAV_IO; }
+    const int64_t fsize = (int64_t)st.st_size;
+    unsigned char h[24];
+    int rc = AFSK_WAV_NO_DATA;
+    if (fsize < 12 || !pread_all(fd, h, 12, 0) || std::memcmp(h, "RIFF", 4) != 0 ||
+        std::memcmp(h + 8, "WAVE", 4) != 0) {
+        close(fd);
+        return AFSK_WAV_NOT_RIFF;
+    }
+    // chunks inside the RIFF form end where the RIFF size says (Chunk.read clips to it), or at EOF
+    const int64_t form_end = std::min<int64_t>(fsize, 8 + (int64_t)le32(h + 4));
+    int64_t pos = 12;
+    int64_t framesize = 0;
+    while (pos + 8 <= form_end) {
+        if (!pread_all(fd, h, 8, pos)) { rc = AFSK_WAV_IO; break; }
+        const int64_t csize = (int64_t)le32(h + 4);
+        const int64_t body = pos + 8;
+        if (std::memcmp(h, "fmt ", 4) == 0) {
+            const int64_t have = std::min<int64_t>(csize, form_end - body);
+            if (have < 16 || !pread_all(fd, h, 16, body)) { rc = AFSK_WAV_FORMAT; break; }
+            const uint32_t tag = le16(h), channels = le16(h + 2), bits = le16(h + 14);
+            const uint32_t width = (bits + 7) / 8;
+            if (tag != 1 || channels == 0 || width == 0) { rc = AFSK_WAV_FORMAT; break; }
+            framesize = (int64_t)channels * width;
+        } else if (std::memcmp(h, "data", 4) == 0) {
+            if (framesize == 0) { rc = AFSK_WAV_NO_DATA; break; }       // 'data' before 'fmt '
+            const int64_t want = (csize / framesize) * framesize;      // getnframes() whole frames
+            const int64_t avail = std::max<int64_t>(0, form_end - body);
+            *data_off = body;
+            *data_bytes = std::min(want, avail);
+            rc = AFSK_WAV_OK;
+            break;
+        }
+        pos = body + csize + (csize & 1);                               // chunks are padded to even sizes
+    }
+    close(fd);
+    return rc;
 }
 
 #define AFSK_HIP(call, what)                             \
@@ -496,6 +657,112 @@ int afsk_demod_streams_host(const int16_t* const* streams, const int32_t* stream
         return demod_streams_host_impl(streams, stream_len, bit_frames, amp_end_threshold, n_streams,
                                        out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx,
                                        out_term_frame, out_status);
+    });
+}
+
+int afsk_wav_probe(const char* const* paths, int32_t n_files, int64_t* out_data_offset,
+                   int64_t* out_data_bytes, int32_t* out_status) {
+    if (n_files < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (n_files == 0) return AFSK_OK;
+    if (!paths || !out_data_offset || !out_data_bytes || !out_status)
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    for (int32_t i = 0; i < n_files; i++)
+        if (!paths[i]) return fail(AFSK_E_INVALID_ARG, "null path");
+    return no_throw([&] {
+        parallel_for((size_t)n_files, io_threads(), [&](size_t i) {
+            out_status[i] = wav_probe_one(paths[i], &out_data_offset[i], &out_data_bytes[i]);
+        });
+        return AFSK_OK;
+    });
+}
+
+static int wav_upload_impl(const char* const* paths, const int64_t* data_offset, const int64_t* data_bytes,
+                           const int64_t* stream_offset, int32_t n_files, int16_t* d_samples,
+                           int64_t capacity_samples) {
+    if (n_files < 0 || capacity_samples < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (n_files == 0) return AFSK_OK;
+    if (!paths || !data_offset || !data_bytes || !stream_offset || !d_samples)
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    const size_t n = (size_t)n_files;
+    int64_t prev_end = 0;
+    for (size_t s = 0; s < n; s++) {
+        if (!paths[s] || data_offset[s] < 0 || data_bytes[s] < 0 || stream_offset[s] < prev_end)
+            return fail(AFSK_E_INVALID_ARG, "streams must be ascending and must not overlap");
+        prev_end = stream_offset[s] + data_bytes[s] / 2;
+        if (prev_end > capacity_samples) return fail(AFSK_E_INVALID_ARG, "stream outside the device buffer");
+    }
+    if (int rc0 = require_device()) return rc0;
+    int rc = AFSK_OK;
+    hipStream_t stream = nullptr;
+    {
+        hipError_t e = g_thread_stream.get(&stream);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
+    }
+    ScratchLease lease;
+    char* d_unused = nullptr;
+    char* stage[2];
+    hipEvent_t stage_free[2];
+    {
+        hipError_t e = lease.acquire(1, &d_unused, /*block=*/true);    // owns the staging windows
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-entry scratch)");
+        e = lease.staging(&stage[0], &stage[1], &stage_free[0], &stage_free[1]);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (staging)");
+    }
+    std::vector<int> fds(n, -1);
+    std::atomic<int> io_failed{-1};
+    struct Piece { size_t file; int64_t file_off; char* dst; size_t bytes; bool last; };
+    {
+        // windows over the device byte range the streams cover; a window holds whole or partial
+        // streams, each read by one pread straight into pinned memory
+        const size_t first_b = (size_t)stream_offset[0] * 2;
+        const size_t all_end = (size_t)prev_end * 2;
+        const size_t span = all_end - first_b;
+        const size_t win = std::min(kStageBytes, std::max((size_t)1 << 20, ((span / 4) + 65535) & ~(size_t)65535));
+        size_t s_cur = 0;
+        std::vector<Piece> pieces;
+        for (size_t w0 = first_b, k = 0; w0 < all_end; w0 += win, k++) {
+            const size_t w1 = std::min(all_end, w0 + win);
+            char* st = stage[k & 1];
+            if (k >= 2) AFSK_HIP(hipEventSynchronize(stage_free[k & 1]), "hipEventSynchronize");
+            pieces.clear();
+            for (size_t s = s_cur; s < n; s++) {
+                const size_t b0 = (size_t)stream_offset[s] * 2, b1 = b0 + ((size_t)data_bytes[s] & ~(size_t)1);
+                if (b0 >= w1) break;
+                if (b1 <= w0) { s_cur = s + 1; continue; }
+                const size_t lo = std::max(b0, w0), hi = std::min(b1, w1);
+                pieces.push_back({s, data_offset[s] + (int64_t)(lo - b0), st + (lo - w0), hi - lo, hi == b1});
+            }
+            parallel_for(pieces.size(), io_threads(), [&](size_t i) {
+                const Piece& p = pieces[i];
+                if (fds[p.file] < 0) fds[p.file] = open(paths[p.file], O_RDONLY | O_CLOEXEC);
+                if (fds[p.file] < 0 || !pread_all(fds[p.file], p.dst, p.bytes, p.file_off))
+                    io_failed.store((int)p.file);
+                if (p.last && fds[p.file] >= 0) {           // closed here, in parallel, not in a serial loop at the end
+                    close(fds[p.file]);
+                    fds[p.file] = -1;
+                }
+            });
+            if (io_failed.load() >= 0) {
+                rc = fail(AFSK_E_HOST, std::string("cannot read ") + paths[io_failed.load()]);
+                goto done;
+            }
+            AFSK_HIP(hipMemcpyAsync((char*)d_samples + w0, st, w1 - w0, hipMemcpyHostToDevice, stream), "H2D samples");
+            AFSK_HIP(hipEventRecord(stage_free[k & 1], stream), "hipEventRecord");
+        }
+    }
+    AFSK_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize");
+done:
+    if (rc != AFSK_OK) (void)hipStreamSynchronize(stream);   // nothing may still read the staging windows
+    for (int fd : fds)
+        if (fd >= 0) close(fd);
+    return rc;
+}
+
+int afsk_wav_upload(const char* const* paths, const int64_t* data_offset, const int64_t* data_bytes,
+                    const int64_t* stream_offset, int32_t n_files, int16_t* d_samples,
+                    int64_t capacity_samples) {
+    return no_throw([&] {
+        return wav_upload_impl(paths, data_offset, data_bytes, stream_offset, n_files, d_samples, capacity_samples);
     });
 }
 

@@ -147,6 +147,41 @@ int afsk_demod_streams_host(const int16_t *const *streams, const int32_t *stream
 int afsk_host_scratch_release(void);
 
 /*
+ * .wav container ingest at scale (replaces SoundInput.loadFromFile,
+ * afskmodem.py:213-217, for many files).  Two steps so that the caller owns the device buffer:
+ *
+ * afsk_wav_probe   walks the RIFF chunks of every file exactly like the stdlib `wave` reader the
+ *   reference calls (:214): 'RIFF' <size> 'WAVE', then chunks with even padding; 'fmt ' must
+ *   come before 'data'; the walk stops at 'data'.  Like the reference, rate / width / channel
+ *   count are NOT interpreted -- they only bound the byte count:
+ *   readframes(getnframes()) returns (data_size / (channels * bytes_per_sample)) whole frames,
+ *   clipped to what the file really holds.  Host-only (no HIP call); parallel over files.
+ *     out_data_offset [n] byte offset of the data chunk's payload in the file
+ *     out_data_bytes  [n] bytes readframes(getnframes()) would return (may be odd:
+ *                         __convertFrames (:201-205) then drops the last byte)
+ *     out_status      [n] AFSK_WAV_*; anything but AFSK_WAV_OK means "not a plain PCM RIFF file,
+ *                         or unreadable" -- the Python host re-opens such a file with the stdlib
+ *                         reader so that the caller sees the reference's own exception
+ *
+ * afsk_wav_upload  reads data_bytes[s] & ~1 bytes at data_offset[s] of file s with pread()
+ *   STRAIGHT INTO the library's two pinned staging windows (one copy: page cache -> pinned
+ *   memory, a few threads in parallel) and sends each window to
+ *   d_samples[stream_offset[s] ..] while the next one is being filled.  stream_offset is in
+ *   samples, ascending, streams must not overlap and must fit capacity_samples.  Synchronous for
+ *   the caller, on the calling thread's private non-blocking stream.
+ */
+#define AFSK_WAV_OK 0
+#define AFSK_WAV_IO 1          /* cannot open / read                                      */
+#define AFSK_WAV_NOT_RIFF 2    /* no 'RIFF' .. 'WAVE' header                              */
+#define AFSK_WAV_NO_DATA 3     /* 'fmt ' and/or 'data' chunk missing, or 'data' first     */
+#define AFSK_WAV_FORMAT 4      /* format tag other than PCM, zero channels / sample width */
+int afsk_wav_probe(const char *const *paths, int32_t n_files, int64_t *out_data_offset,
+                   int64_t *out_data_bytes, int32_t *out_status);
+int afsk_wav_upload(const char *const *paths, const int64_t *data_offset, const int64_t *data_bytes,
+                    const int64_t *stream_offset, int32_t n_files, int16_t *d_samples,
+                    int64_t capacity_samples);
+
+/*
  * On-device input synthesis: Transmitter.__getFrames (:452-469) with ECC.encode
  * (:166-175) and, when wav_quirk != 0, SoundOutput.__convertFrames' decimate-by-2
  * + duplicate (:239-244), written to samples[stream_offset[s] .. +stream_len[s])

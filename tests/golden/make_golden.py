@@ -434,6 +434,62 @@ def main():
                           "nbytes": nbytes, "n_frames_ref": len(got), "frames_sha256": sha(got)})
     G["wav_ingest"] = wav_cases
 
+    # ---- 5d. .wav ingest on hand-built RIFF files: extra chunks, odd / clipped data sizes, and the
+    # files the stdlib reader behind ref:214 rejects (exception type + message recorded)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.golden_inputs import build_riff
+    F16 = {"tag": 1, "channels": 1, "rate": 48000, "bits": 16}
+    raw = {
+        "list_before_data": {"chunks": [["fmt ", "fmt", F16, None], ["LIST", "hex", "494e464f49534654050000004166736b00", None],
+                                        ["data", "pattern", 9000, None]]},
+        "odd_chunk_before_data": {"chunks": [["fmt ", "fmt", F16, None], ["junk", "pattern", 25, None], ["data", "pattern", 5000, None]]},
+        "chunk_after_data": {"chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 5000, None], ["LIST", "pattern", 40, None]]},
+        "odd_data_size": {"chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 4001, None]]},
+        "odd_data_then_chunk": {"chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 4001, None], ["cue ", "pattern", 12, None]]},
+        "stereo_partial_frame": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 2, "rate": 44100, "bits": 16}, None],
+                                            ["data", "pattern", 4002, None]]},
+        "width3_partial_frame": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 1, "rate": 48000, "bits": 24}, None],
+                                            ["data", "pattern", 4000, None]]},
+        "bits12": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 1, "rate": 48000, "bits": 12}, None], ["data", "pattern", 3001, None]]},
+        "data_longer_than_file": {"chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 6001, 10000, False]]},
+        "riff_size_cuts_data": {"riff_size": 4 + 24 + 8 + 3000, "chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 8000, None]]},
+        "riff_size_too_big": {"riff_size": 1 << 20, "chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 5000, None]]},
+        "fmt18": {"chunks": [["fmt ", "fmt", dict(F16, extra_hex="0000"), None], ["data", "pattern", 4000, None]]},
+        "two_fmt": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 2, "rate": 8000, "bits": 16}, None], ["fmt ", "fmt", F16, None],
+                               ["data", "pattern", 4002, None]]},
+        "empty_data": {"chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 0, None]]},
+        "data_smaller_than_frame": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 2, "rate": 48000, "bits": 16}, None], ["data", "pattern", 3, None]]},
+        # rejected by the reader
+        "not_riff": {"magic": "RIFX", "chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 100, None]]},
+        "not_wave": {"form": "AVI ", "chunks": [["fmt ", "fmt", F16, None], ["data", "pattern", 100, None]]},
+        "no_data_chunk": {"chunks": [["fmt ", "fmt", F16, None], ["LIST", "pattern", 10, None]]},
+        "data_before_fmt": {"chunks": [["data", "pattern", 100, None], ["fmt ", "fmt", F16, None]]},
+        "float_format": {"chunks": [["fmt ", "fmt", {"tag": 3, "channels": 1, "rate": 48000, "bits": 32}, None], ["data", "pattern", 400, None]]},
+        "zero_channels": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 0, "rate": 48000, "bits": 16}, None], ["data", "pattern", 400, None]]},
+        "zero_bits": {"chunks": [["fmt ", "fmt", {"tag": 1, "channels": 1, "rate": 48000, "bits": 0}, None], ["data", "pattern", 400, None]]},
+        "short_fmt": {"chunks": [["fmt ", "hex", "0100010080bb000000770100", None], ["data", "pattern", 400, None]]},
+        "chunk_overruns_form": {"riff_size": 4 + 24 + 8 + 10, "chunks": [["fmt ", "fmt", F16, None], ["junk", "pattern", 100, None],
+                                                                         ["data", "pattern", 400, None]]},
+        "too_short_file": {"chunks": []},
+    }
+    raw_cases = []
+    for name, rc in raw.items():
+        rc = dict({"magic": "RIFF", "form": "WAVE", "riff_size": "auto"}, **rc)
+        blob = build_riff(json.loads(json.dumps(rc)))       # exactly what a test rebuilds from the fixture
+        if name == "too_short_file":
+            blob = blob[:10]
+        fn = os.path.join(tmpdir, "raw_" + name + ".wav")
+        with open(fn, "wb") as f:
+            f.write(blob)
+        ent = {"name": name, "recipe": rc, "file_sha256": hashlib.sha256(blob).hexdigest(), "truncate_to": 10 if name == "too_short_file" else None}
+        try:
+            got = ref.SoundInput.loadFromFile(fn)
+            ent.update(result="ok", n_frames_ref=len(got), frames_sha256=sha(got))
+        except BaseException as e:  # noqa: BLE001
+            ent.update(result="raises", exc_type=type(e).__name__, exc_msg=str(e))
+        raw_cases.append(ent)
+    G["wav_raw_cases"] = raw_cases
+
     # ---- 6. README assertion (README.md:47-66)
     fn = os.path.join(tmpdir, "afsk.wav")
     ref.Transmitter(1200).save("Héellóo World!", fn)

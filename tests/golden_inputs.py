@@ -71,3 +71,44 @@ def build_capture(recipe) -> np.ndarray:
         else:
             raise ValueError(kind)
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.int16)
+
+
+# ------------------------------------------------------------------ raw RIFF files (wav ingest)
+
+
+def wav_body(n: int) -> bytes:
+    """The byte pattern every wav_ingest case fills its data chunk with."""
+    return bytes(((i * 37 + 11) ^ (i >> 3)) & 0xFF for i in range(n))
+
+
+def fmt_body(tag=1, channels=1, rate=48000, bits=16, extra=b"") -> bytes:
+    import struct
+    width = (bits + 7) // 8
+    return struct.pack("<HHLLHH", tag, channels, rate, rate * channels * width, channels * width, bits) + extra
+
+
+def build_riff(recipe: dict) -> bytes:
+    """File bytes of a wav_raw_cases recipe: {"magic", "form", "riff_size" (int or "auto"),
+    "chunks": [[id, kind, arg, declared_size or None], ...]}; kind "hex" -> bytes.fromhex(arg),
+    "pattern" -> wav_body(arg), "fmt" -> fmt_body(**arg).  A chunk body is padded to an even
+    length (RIFF rule) unless its entry carries a fifth element False."""
+    import struct
+    out = b""
+    for ent in recipe["chunks"]:
+        cid, kind, arg, declared = ent[0], ent[1], ent[2], ent[3]
+        pad = ent[4] if len(ent) > 4 else True
+        if kind == "fmt":
+            kw = dict(arg)
+            if "extra_hex" in kw:
+                kw["extra"] = bytes.fromhex(kw.pop("extra_hex"))
+            body = fmt_body(**kw)
+        else:
+            body = bytes.fromhex(arg) if kind == "hex" else wav_body(arg)
+        size = len(body) if declared is None else declared
+        out += cid.encode("latin-1") + struct.pack("<L", size) + body
+        if pad and len(body) & 1:
+            out += b"\x00"
+    riff = recipe["riff_size"]
+    if riff == "auto":
+        riff = 4 + len(out)
+    return recipe["magic"].encode("latin-1") + struct.pack("<L", riff) + recipe["form"].encode("latin-1") + out

@@ -633,6 +633,41 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
     afskmodem.LOG_LEVEL = 0
 
 
+def test_native_wav_ingest_raw_riff_cases(golden, torch_cuda, tmp_path):
+    """Row f3 on the device: batch.load_wav_batch (afsk_wav_probe + afsk_wav_upload: pread into
+    the pinned windows, H2D) over the hand-built RIFF files equals what the reference's loader
+    returned for each; a file the reference rejects raises the reference's exception."""
+    from tests.test_host_api import _write_raw_cases
+    from tests.golden_inputs import sha_i16
+    cases = _write_raw_cases(golden, tmp_path)
+    ok = [(c, fn) for c, fn in cases if c["result"] == "ok"]
+    samples, off, ln, max_len = batch.load_wav_batch([fn for _, fn in ok] * 3)     # repeated: several windows' worth of files
+    h, ho, hl = samples.cpu().numpy(), off.cpu().numpy(), ln.cpu().numpy()
+    assert max_len == max(c["n_frames_ref"] for c, _ in ok)
+    for i, (c, _) in enumerate(ok * 3):
+        assert hl[i] == c["n_frames_ref"], c["name"]
+        assert ho[i] % 8 == 0
+        assert sha_i16(h[ho[i]: ho[i] + hl[i]]) == c["frames_sha256"], c["name"]
+    for c, fn in cases:
+        if c["result"] != "ok":
+            with pytest.raises(BaseException) as ei:
+                batch.load_wav_batch([ok[0][1], fn, ok[1][1]])
+            assert type(ei.value).__name__ == c["exc_type"] and str(ei.value) == c["exc_msg"], c["name"]
+    # a big batch crossing the 32 MiB staging windows: 700 x 1 s files
+    t = afskmodem.Transmitter(1200)
+    names = []
+    for i in range(700):
+        fn = str(tmp_path / f"big{i}.wav")
+        if i < 8:
+            t.save(bytes([65 + i]) * (20 + i), fn)
+        else:
+            import shutil
+            shutil.copyfile(str(tmp_path / f"big{i % 8}.wav"), fn)
+        names.append(fn)
+    got = afskmodem.Receiver(1200).load_batch(names, string=False)
+    assert got == [bytes([65 + (i % 8)]) * (20 + (i % 8)) for i in range(700)]
+
+
 def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     """The single-pass kernel re-aligns ring reads by (2*ci) & 15: exercise all 8 shifts, ring
     wrap-around on long streams, and tiny symbol counts, for every baud rate of the single-pass

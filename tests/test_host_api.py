@@ -307,3 +307,52 @@ def test_float_thresholds_round_like_the_reference_comparison():
         for a in list(range(base - 3, base + 4)) + [0, 1, 13999, 14000, 14001, 32768]:
             assert (a < T_lt) == (a < t), (a, t, T_lt)
             assert (a > T_gt) == (a > t), (a, t, T_gt)
+
+
+def _write_raw_cases(golden, tmp_path):
+    import hashlib
+    from tests.golden_inputs import build_riff
+    out = []
+    for c in golden["wav_raw_cases"]:
+        blob = build_riff(c["recipe"])
+        if c["truncate_to"] is not None:
+            blob = blob[: c["truncate_to"]]
+        assert hashlib.sha256(blob).hexdigest() == c["file_sha256"], c["name"]
+        fn = str(tmp_path / ("raw_" + c["name"] + ".wav"))
+        with open(fn, "wb") as f:
+            f.write(blob)
+        out.append((c, fn))
+    return out
+
+
+def test_native_riff_walk_matches_the_reference_reader(golden, tmp_path):
+    """Row f3: afsk_wav_probe (host-only) against what SoundInput.loadFromFile (ref:213-217, i.e.
+    the stdlib `wave` chunk walk) returned for hand-built RIFF files: extra / odd-sized chunks
+    around `data`, odd and clipped data sizes, wrong RIFF sizes -- and every file the reference's
+    reader rejects must be flagged (the host then lets the stdlib reader raise)."""
+    cases = _write_raw_cases(golden, tmp_path)
+    off, nbytes, status = batch.wav_probe([fn for _, fn in cases])
+    for (c, fn), o, nb, st in zip(cases, off, nbytes, status):
+        if c["result"] == "ok":
+            assert st == 0, (c["name"], st)
+            assert nb // 2 == c["n_frames_ref"], (c["name"], nb)
+            raw = open(fn, "rb").read()[int(o): int(o) + (int(nb) & ~1)]
+            assert sha_i16(np.frombuffer(raw, "<i2")) == c["frames_sha256"], c["name"]
+            assert sha_i16(batch.read_wav_frames(fn)) == c["frames_sha256"], c["name"]
+        else:
+            assert st != 0, c["name"]
+            with pytest.raises(BaseException) as ei:
+                batch.read_wav_frames(fn)
+            assert type(ei.value).__name__ == c["exc_type"] and str(ei.value) == c["exc_msg"], c["name"]
+    # unreadable path
+    _, _, st = batch.wav_probe([str(tmp_path / "missing.wav")])
+    assert st[0] == 1
+    # the four header-variant files of wav_ingest too
+    import wave
+    for c in golden["wav_ingest"]:
+        fn = str(tmp_path / (c["name"] + "_p.wav"))
+        with wave.open(fn, "wb") as f:
+            f.setnchannels(c["nchannels"]); f.setsampwidth(c["sampwidth"]); f.setframerate(c["framerate"])
+            f.writeframes(bytes(((i * 37 + 11) ^ (i >> 3)) & 0xFF for i in range(c["nbytes"])))
+        o, nb, st = batch.wav_probe([fn])
+        assert st[0] == 0 and nb[0] // 2 == c["n_frames_ref"], c["name"]
