@@ -66,12 +66,12 @@ PAYLOAD_SEED = 2024
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the kernel sources of libafsk_amd.so: ties a committed rocprof figure
-    (profiles/traffic_latest.json) to the build it was measured on."""
+    """sha256 over the demod kernel's sources (afsk_demod*.h/.hip + afsk_kernels.h): ties a
+    committed rocprof figure (profiles/traffic_latest.json) to the kernel it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "afskmodem_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".h", ".hip")):
+        if fn.endswith((".h", ".hip")) and (fn.startswith("afsk_demod") or fn == "afsk_kernels.h"):
             h.update(fn.encode())
             h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
