@@ -635,10 +635,16 @@ def run_rank(args) -> None:
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if ctx.use_dist:
         dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit,
+    # AFTER the result: flush it now so that the JSON line is the last thing on stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main() -> None:

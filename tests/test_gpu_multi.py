@@ -131,3 +131,24 @@ def test_single_rank_rccl_gather_roundtrip():
     p.join(timeout=120)
     assert p.exitcode == 0 and err == "", err
     assert seen == 1 and ok and clean_ok
+
+
+def test_host_entries_follow_the_current_device():
+    """the host-entry scratch cache keeps pinned windows + events between
+    calls; when the current device changes, the events must be recreated on the new device.
+    Needs two GPUs."""
+    import torch
+    from afskmodem_amd import batch
+    from oracle import afsk_oracle as O
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    rng = np.random.default_rng(4)
+    streams = [O.wav_convert(O.get_frames(rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), 1200)) for _ in range(40)]
+    want = None
+    for dev in (0, 1, 0, 1):
+        with torch.cuda.device(dev):
+            got = batch.demod_host_arrays(streams, 40)      # gather entry: pinned windows + events
+            one = batch.demod_host_flat(streams[0], [0], [len(streams[0])], 40)
+        if want is None:
+            want = got
+        assert got.payloads() == want.payloads() and one.payloads()[0] == want.payloads()[0], dev
