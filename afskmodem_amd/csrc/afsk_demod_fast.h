@@ -35,12 +35,32 @@ namespace afsk {
 
 constexpr int kRingBytes = 16384;
 constexpr int kRingChunks = 16;
+// L2 warming behind the ring start (r2).  While a wave computes phase A its 16 ring chunks have
+// landed and it has nothing in flight -- LDS caps the ring at 16 KiB.  Right behind the 16 chunk
+// requests the wave therefore asks for one dword of every 64 bytes of stream bytes 16 KiB .. 24 KiB
+// (two LDS-DMA instructions into a 256-byte dummy area, default cache policy): the lines are
+// fetched HBM -> L2 during phase A and the real requests for chunks 16..23 then hit in L2.
+// Worth 2.7-4 % in steady state (16384+ streams); at 4096 streams, where all waves of a generation
+// start together, it costs 1-2 %, so it is only armed for launches of kWarmMinStreams or more.
+// A run-ahead kept up for the whole stream (two more warming requests per round) is 10 % SLOWER:
+// every line is then requested twice and the request path, not HBM, becomes the limit.
+constexpr int kWarmOps = 2;
+constexpr int kWarmMinStreams = 8192;
 
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
     uint8_t* ring;                 // wave-uniform LDS base of the 16 KiB ring
     int lane;
     int next;                      // next chunk id to issue
+    int warm_ops = 0;              // warming requests issued between chunk 15 and chunk 16 (0 or kWarmOps)
+
+    // Requests complete in issue order, so chunk `need` has landed once at most as many requests as
+    // were issued after it are outstanding; FIXED = that count without the warming requests.
+    template <int FIXED>
+    __device__ __forceinline__ void wait_fixed(int need) {
+        if (warm_ops != 0 && need < kRingChunks) wait_vmcnt_dyn(FIXED + warm_ops);
+        else wait_vmcnt<FIXED>();
+    }
 
     template <int AUX = 0>
     __device__ __forceinline__ void issue(int c) {
@@ -108,8 +128,9 @@ constexpr int kMirrorBytes = 256;                              // copy of ring b
                                                                // piece may run linearly past the ring end (wm_rounds)
 constexpr int kBitBufOffset = kRingBytes + kMirrorBytes;       // phase C's 64-word bit buffer behind the mirror
 constexpr int kBitBufBytes = 512;
-constexpr int kFastWaveLdsProduct = kBitBufOffset + kBitBufBytes;   // 16.75 KiB per wave: what the product build needs
-static_assert(kBitBufOffset + kBitBufBytes <= kFastWaveLds, "bit buffer outside the diagnostic build's LDS");
+constexpr int kWarmDummyOffset = kBitBufOffset + kBitBufBytes;  // 256 bytes the warming requests may scribble on
+constexpr int kFastWaveLdsProduct = kWarmDummyOffset + 256;     // 17 KiB per wave: what the product build needs
+static_assert(kWarmDummyOffset + 256 <= kFastWaveLds, "bit buffer / dummy area outside the diagnostic build's LDS");
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
@@ -294,7 +315,7 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     const int lane = fr.lane;
     using std::integral_constant;
 
-    wait_vmcnt<PRE - 8>();                                    // chunks 0..7 (samples 0..4095) have landed
+    fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
     const int ll = lane < L::LANES ? lane : L::LANES - 1;    // idle lanes re-read the last window
     const uint8_t* src = fr.ring + (GC * 2) * ll;
@@ -379,7 +400,7 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
     const int lane = fr.lane;
     using std::integral_constant;
 
-    wait_vmcnt<PRE - 8>();                                    // chunks 0..7 (samples 0..4095) have landed
+    fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
     // total(0) = C + sum_j sigma_j x[j]: lane l < N/8 takes samples 8l .. 8l+7 (one sign)
     uint32_t base;
@@ -821,7 +842,7 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
         // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
         // 10 youngest DMAs may still be in flight.
-        wait_vmcnt<10>();
+        fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
         if constexpr (BF == 20) {
@@ -937,7 +958,7 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
     for (int r = 0; r < NR; r++) {
         // bytes [byte0 + 1024 R r, +1024 R) must have landed: at most R + 1 chunks from the oldest
         // resident one; chunks through B_r + 15 are issued, so the 15 - R youngest may be in flight
-        wait_vmcnt<kRingChunks - 1 - R>();
+        fr.template wait_fixed<kRingChunks - 1 - R>(((byte0 + 1024 * R * r) >> 10) + R);
         uint32_t x[SPL * NO];
         const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
 #pragma unroll
@@ -1088,7 +1109,8 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
-        wait_vmcnt_dyn(fr.next - 1 - (last >> 10));               // chunks through last >> 10 have landed
+        wait_vmcnt_dyn(fr.next - 1 - (last >> 10) +               // chunks through last >> 10 have landed
+                       ((last >> 10) < kRingChunks ? fr.warm_ops : 0));
         const int rb = pos & (kRingBytes - 1);                    // wave-uniform
         if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
@@ -1195,7 +1217,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   uint8_t* out_row, int out_stride, int& ci_out,
                                                   int32_t& n_sym_out,
                                                   unsigned long long* stamps = nullptr,
-                                                  int32_t* margins = nullptr, int32_t mstride = 0) {
+                                                  int32_t* margins = nullptr, int32_t mstride = 0,
+                                                  bool warm = false) {
     constexpr bool MULTI = MultiGeom<BF>::valid;
     constexpr bool WM = WmGeom<BF>::valid;
     constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : 2560 / BF);   // symbols per round
@@ -1210,10 +1233,17 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
 #pragma unroll
     for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
     fr.next = PRE;
+    if (warm && !OLD_SYNC) {
+#pragma unroll
+        for (int p = 0; p < kWarmOps; p++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(fr.rsrc, AFSK_LDS(lds + kWarmDummyOffset), 4, lane * 64,
+                                                     kRingBytes + 4096 * p, 0, 0);
+        fr.warm_ops = kWarmOps;
+    }
 
     int ci = 0;
     if constexpr (FLAGS & 1) {
-        wait_vmcnt<PRE - 8>();
+        fr.template wait_fixed<PRE - 8>(7);
     } else {
         // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
         // not: 72 + 320 samples), sub-windows in steps otherwise

@@ -426,15 +426,13 @@ __device__ __forceinline__ void demod_symbols(const int16_t* xs, int32_t len, in
 
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {          // n is wave-uniform
     switch (n) {
-        case 0: wait_vmcnt<0>(); break;    case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;    case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;    case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;    case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;    case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;  case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break;  case 13: wait_vmcnt<13>(); break;
-        case 14: wait_vmcnt<14>(); break;
-        default: if (n < 0) wait_vmcnt<0>(); else wait_vmcnt<15>(); break;
+#define AFSK_W(k) case k: wait_vmcnt<k>(); break;
+        AFSK_W(0) AFSK_W(1) AFSK_W(2) AFSK_W(3) AFSK_W(4) AFSK_W(5) AFSK_W(6) AFSK_W(7)
+        AFSK_W(8) AFSK_W(9) AFSK_W(10) AFSK_W(11) AFSK_W(12) AFSK_W(13) AFSK_W(14) AFSK_W(15)
+        AFSK_W(16) AFSK_W(17) AFSK_W(18) AFSK_W(19) AFSK_W(20) AFSK_W(21) AFSK_W(22) AFSK_W(23)
+        AFSK_W(24) AFSK_W(25) AFSK_W(26) AFSK_W(27) AFSK_W(28) AFSK_W(29) AFSK_W(30)
+#undef AFSK_W
+        default: if (n < 0) wait_vmcnt<0>(); else wait_vmcnt<31>(); break;
     }
 }
 
@@ -574,17 +572,18 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     bool done = false;
     if constexpr (FAST) {   // single-pass ring kernel for the common bauds (afsk_demod_fast.h)
         unsigned long long* stamps = (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr;
+        const bool warm = a.n_streams >= kWarmMinStreams;          // wave-uniform (afsk_demod_fast.h)
         done = true;
         switch (bf) {
-            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
-            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
-#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
+            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
+#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
             AFSK_FAST_CASE(4) AFSK_FAST_CASE(8) AFSK_FAST_CASE(12) AFSK_FAST_CASE(16)
             AFSK_FAST_CASE(24) AFSK_FAST_CASE(32) AFSK_FAST_CASE(48) AFSK_FAST_CASE(64)
             AFSK_FAST_CASE(60) AFSK_FAST_CASE(96) AFSK_FAST_CASE(100) AFSK_FAST_CASE(120)
 #undef AFSK_FAST_CASE
-            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
-            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride); break;
+            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
+            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
             default:  done = false; break;
         }
     }

@@ -705,6 +705,51 @@ def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     assert (got.nbytes > 100).any() and (got.nbits % 14 != 0).any()
 
 
+def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
+    """Launches of 8192+ streams arm the L2 warming requests behind the ring start (kWarmMinStreams,
+    afsk_demod_fast.h), which shifts the in-flight accounting of the first rounds on every
+    single-pass path: 8256 short streams cycling through all 16 single-pass baud rates (plus one
+    two-pass rate), ragged lengths around the 24 KiB the warming covers, odd leads, some noisy --
+    every output equals the CPU oracle's."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    bauds_all = (300, 400, 480, 500, 600, 750, 800, 1000, 1200, 1500, 2000, 2400, 3000, 4000, 6000, 12000, 200)
+    n = 8256
+    protos = {}
+    for baud in bauds_all:
+        t = afskmodem.Transmitter(baud, 0.08)
+        ws = []
+        for k in range(4):
+            data = rng.integers(0, 256, 3 + k, dtype=np.uint8).tobytes()
+            ws.append(t.frames(data) if baud == 12000 else t.wav_samples(data))
+        protos[baud] = ws
+    pieces, bfs = [], []
+    for i in range(n):
+        baud = bauds_all[i % len(bauds_all)]
+        w = protos[baud][(i // len(bauds_all)) % 4]
+        lead = int(rng.integers(0, 40)) if i % 3 else 0
+        x = np.concatenate([np.zeros(lead, np.int16), w])
+        L = int(rng.integers(11000, 15000)) if i % 5 else len(x)
+        x = x[:L] if L <= len(x) else np.concatenate([x, np.zeros(L - len(x), np.int16)])
+        if i % 7 == 0:
+            x = np.clip(x.astype(np.int32) + rng.integers(-6000, 6000, len(x)), -32768, 32767).astype(np.int16)
+        pieces.append(x); bfs.append(48000 // baud)
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    bf = np.array(bfs, np.int32)
+    flat = np.concatenate(pieces)
+    stride = 64
+    got = device_demod(torch, flat, off, ln, bf, stride=stride)
+    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=16)
+    assert_same(got, want, "large launch")
+    assert (got.nbytes > 0).sum() > n // 2
+    # the same streams in a launch below the threshold give the same answers (warming is timing only)
+    sub = slice(0, 4096)
+    got2 = device_demod(torch, flat[: int(off[4096])], off[sub], ln[sub], bf[sub], stride=stride)
+    for f in FIELDS:
+        assert np.array_equal(getattr(got2, f), getattr(got, f)[sub]), f
+
+
 def test_full_size_config3_mixed_baud_roundtrip(torch_cuda):
     """BASELINE config #3 at full size (65536 x 1 s, baud = {300,1200,2400} by stream index,
     6.3 GB): size-independent round trip (decoded == modulated payload for every stream) and
