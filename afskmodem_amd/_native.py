@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libafsk_amd.so")
+# AFSK_AMD_LIB: another build of the same library (kernel A/B runs of bench.py with tools/build_variant.sh)
+LIB_PATH = os.environ.get("AFSK_AMD_LIB") or os.path.join(_HERE, "csrc", "libafsk_amd.so")
 
 OK = 0
 E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP, E_HOST = -1, -2, -3, -4, -5
