@@ -367,6 +367,9 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
         "steps": steps, "warmup": warmup, "preroll_launches": preroll_launches,
         "value": round(samples_per_step * steps / elapsed / 1e6, 1),            # wall clock, fences included
         "value_event_time": round(samples_per_step * steps / (event_ms * 1e-3) / 1e6, 1),   # HIP events
+        # the same wall-clock rate counting only the samples the reference has to read (up to the
+        # squelch-triggering symbol); `value` counts every sample of the buffers, tail silence included
+        "value_active_samples": round(float(active.sum()) * ctx.world * steps / elapsed / 1e6, 1),
         "unit": "Msamples/s",
         "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 5),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
@@ -550,6 +553,7 @@ def run_rank(args) -> None:
                    "stream_len": STREAM_LEN, "bauds": list(sh.bauds), "snr_db": sh.snr_db,
                    "parallelism": f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")},
         "value_event_time": rec["value_event_time"],
+        "value_active_samples": rec["value_active_samples"],
         "roofline": rec["roofline"],
         "kernel_source_hash": src_hash,
         "input_buffers_rotated": rec["input_buffers_rotated"],
@@ -566,7 +570,7 @@ def run_rank(args) -> None:
     if world == 1 and not args.no_cpu_baseline:
         from oracle import afsk_oracle as O   # checker + reported CPU baseline only
         res, got_payloads = aux["res"], aux["got_payloads"]
-        ns = args.cpu_sample_streams or min(sh.n_local, 2048)
+        ns = args.cpu_sample_streams or min(sh.n_local, 4096)
         rate, _, (h, h_off, h_ln) = oracle_match(sh, res, got_payloads, sh.inputs[0], ns, cores)
         n1 = max(ns // 8, 1)
         t1 = time.perf_counter()
