@@ -721,13 +721,22 @@ __device__ __forceinline__ uint64_t compress_bits(uint64_t x) {
         x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
         x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
         x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-    } else {
-        static_assert(LPS == 4, "two or four lanes per symbol");
+    } else if constexpr (LPS == 4) {
         x &= 0x1111111111111111ull;
         x = (x | (x >> 3)) & 0x0303030303030303ull;
         x = (x | (x >> 6)) & 0x000F000F000F000Full;
         x = (x | (x >> 12)) & 0x000000FF000000FFull;
         x = (x | (x >> 24)) & 0x000000000000FFFFull;
+    } else if constexpr (LPS == 8) {
+        x &= 0x0101010101010101ull;
+        x = (x | (x >> 7)) & 0x0003000300030003ull;
+        x = (x | (x >> 14)) & 0x0000000F0000000Full;
+        x = (x | (x >> 28)) & 0x00000000000000FFull;
+    } else {
+        static_assert(LPS == 16, "2, 4, 8 or 16 lanes per symbol");
+        x &= 0x0001000100010001ull;
+        x = (x | (x >> 15)) & 0x0000000300000003ull;
+        x = (x | (x >> 30)) & 0x000000000000000Full;
     }
     return x;
 }
@@ -1209,6 +1218,257 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         });
         if (rd.st.phase == 2) break;
     }
+}
+
+// ---- every other valid bit_frames (a RUNTIME value) on the single-pass ring -------------------
+// bit_frames 128 and above (375 baud and below: outside the reference's documented range, but its
+// code decodes them).  Same ring, watermark refill and mirror as wm_rounds; the symbol geometry is
+// computed at run time:
+//   * lps lanes per symbol (2, 4, 8 or 16: the largest split that keeps a lane piece an even number
+//     of samples and, where possible, at most 64 samples), spp symbols per round (a power of two, a
+//     round of at most 8 KiB); a lane walks its piece dword by dword (ds_read_b32 -- gfx950 reads
+//     2-byte-aligned dwords too, so there is no re-aligning path), building the mark / space template
+//     of each sample from its phase in the symbol; the lps partial sums are added with DPP
+//     (quad_perm, row_half_mirror, row_mirror);
+//   * clock recovery: the sub-window form in steps of 64 x 24 offsets with run-time lags (seven
+//     2-byte-aligned 48-byte sub-windows per lane and step), run twice -- once for the minimum, once
+//     for the first offset under the bound -- because the totals of a run-time number of steps
+//     cannot stay in registers.
+typedef u32x4 u32x4_a2 __attribute__((aligned(2)));
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+
+__device__ __forceinline__ uint64_t compress_bits_rt(uint64_t x, int lps) {
+    switch (lps) {
+        case 2: return compress_bits<2>(x);
+        case 4: return compress_bits<4>(x);
+        case 8: return compress_bits<8>(x);
+        default: return compress_bits<16>(x);
+    }
+}
+
+// sum over the lps lanes of an aligned group, result in every lane of the group
+__device__ __forceinline__ uint32_t group_sum_rt(uint32_t v, int lps) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);               // quad_perm [1,0,3,2]
+    if (lps >= 4) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    if (lps >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); // row_half_mirror
+    if (lps >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);// row_mirror
+    return v;
+}
+
+// rxd_pass with a run-time pass size ps (a power of two below 64; k0 % ps == 0)
+template <class AmpFn>
+__device__ __forceinline__ void rxd_pass_rt(RxDeferred& d, uint64_t bmask, int nv, int k0, int ps, int lane,
+                                            unsigned long long* words, uint8_t* out_row, int out_stride,
+                                            AmpFn&& amp_ok_mask) {
+    const int start = rx_training(d.st, bmask, nv, k0);
+    if (start >= 0 && start < nv) rxd_stop(d, amp_ok_mask(), start, nv, k0);
+    const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    d.filled = k0 + ps;
+    d.cur |= (bmask & valid) << (k0 & 63);
+    if (((k0 & 63) + ps) == 64) {
+        if (lane == 0) words[(k0 >> 6) & (kBitWords - 1)] = d.cur;
+        d.cur = 0;
+    }
+    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
+        rxd_flush<32>(d, k0 + nv, lane, words, out_row, out_stride);
+}
+
+template <bool FIND>
+__device__ __forceinline__ void clock_sweep_rt(FastRing& fr, int bf, uint32_t base0, uint32_t bound,
+                                               uint32_t& min_total, uint32_t& cand) {
+    constexpr int GC = 24, STEP = 64 * GC;
+    const int lane = fr.lane;
+    const int N = 2 * bf, q = bf >> 2, h = bf >> 1, NOFF = kSync - N;
+    const int T = (NOFF + STEP - 1) / STEP;
+    const int lag[7] = {0, q, 2 * q, 3 * q, bf, bf + h, N};
+    constexpr int coef[7] = {1, -2, 2, -2, 2, -2, 1};
+    uint32_t base = base0;
+    for (int t = 0; t < T; t++) {
+        const int f = STEP * t + GC * lane;
+        const int fa = f < NOFF ? f : NOFF - 1;                 // lanes past the last offset read inside the window
+        const uint8_t* src = fr.ring + 2 * fa;
+        uint32_t R[7][GC / 2];
+#pragma unroll
+        for (int e = 0; e < 7; e++) {
+#pragma unroll
+            for (int j = 0; j < GC / 8; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4_a2*>(src + 2 * lag[e] + 16 * j);
+                R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
+            }
+        }
+        int32_t run[GC];                                        // run[k] = total(f + k + 1) - total(f)
+        int32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+#pragma unroll
+            for (int e = 0; e < 7; e++) {
+                const uint32_t c = (uint32_t)(uint16_t)(int16_t)coef[e];
+                acc = dot2_i16(R[e][k >> 1], (k & 1) ? (c << 16) : c, acc);
+            }
+            run[k] = acc;
+        }
+        const int32_t incl = wave_incl_scan_dpp(acc);
+        const uint32_t first = base + (uint32_t)(incl - acc);
+        base += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+            uint32_t tot = k == 0 ? first : first + (uint32_t)run[k - 1];
+            const int i = f + k;
+            tot = i < NOFF ? tot : 0xFFFFFFFFu;
+            if constexpr (FIND) cand = (tot < bound && (uint32_t)i < cand) ? (uint32_t)i : cand;
+            else min_total = tot < min_total ? tot : min_total;
+        }
+    }
+}
+
+__device__ __forceinline__ int recover_clock_index_rt(FastRing& fr, int bf) {
+    const int lane = fr.lane;
+    const int N = 2 * bf, q = bf >> 2, h = bf >> 1;
+    fr.template wait_fixed<kRingChunks - 8>(7);                 // chunks 0..7 (samples 0..4095) have landed
+    // total(0) = 65535 * bf + sum_j sigma_j x[j] over the 2*bf template samples (ref:80-91): dword m =
+    // samples 2m, 2m + 1, lanes stride through the bf dwords
+    uint32_t base0;
+    {
+        const float rcp_q = 1.0f / (float)q;
+        int32_t a = 0;
+        for (int m = lane; m < bf; m += 64) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(fr.ring + 4 * m);
+            uint32_t cf = 0;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int j = 2 * m + half;
+                const bool hi = j < bf ? ((div_exact((uint32_t)j, (uint32_t)q, rcp_q) & 1u) == 0) : ((j - bf) < h);
+                cf |= (hi ? 0xFFFFu : 0x0001u) << (16 * half);    // sigma = -1 where the template is 32767
+            }
+            a = dot2_i16(w, cf, a);
+        }
+        const int32_t sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(a), 63);
+        base0 = 65535u * (uint32_t)bf + (uint32_t)sum;
+    }
+    uint32_t min_total = 0xFFFFFFFFu, cand = 0xFFFFFFFFu;
+    clock_sweep_rt<false>(fr, bf, base0, 0u, min_total, cand);
+    const uint32_t m = wave_min_u32(min_total);
+    const uint32_t bound = (div_exact(m, (uint32_t)N, 1.0f / (float)N) + 1u) * (uint32_t)N;   // (min mean + 1) * N
+    clock_sweep_rt<true>(fr, bf, base0, bound, min_total, cand);
+    return (int)wave_min_u32(cand);                             // first index of the minimal mean (ref:332-337)
+}
+
+template <int FLAGS>
+__device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp, int byte0, int32_t K,
+                                          int32_t NR, uint32_t amp_thr, RxDeferred& rd,
+                                          unsigned long long* words, uint8_t* out_row, int out_stride,
+                                          int32_t* margins, int32_t mstride) {
+    const int lane = fr.lane;
+    const int q = bf >> 2, h = bf >> 1;
+    const int pl = bf / lps;                                     // samples per lane piece (even)
+    const int rbytes = spp * 2 * bf;                             // bytes per round
+    const int part = lane & (lps - 1);
+    const int sym = lane / lps;                                  // symbol of the round this lane works on
+    const bool active = sym < spp;
+    const int32_t mlim = K < mstride ? K : mstride;
+    const float rcp_q = 1.0f / (float)q, rcp_bf = 1.0f / (float)bf;
+    const int ph0 = part * pl;                                   // phase of the piece's first sample
+    const uint32_t qi0 = div_exact((uint32_t)ph0, (uint32_t)q, rcp_q);
+    const int qp0 = ph0 - (int)qi0 * q;
+    int pos = byte0;                                             // stream byte of the round's first sample
+    for (int r = 0; r < NR; r++, pos += rbytes) {
+        const int last = pos + rbytes + 3;                       // a 2-byte-aligned dword may reach 2 bytes further
+        wait_vmcnt_dyn(fr.next - 1 - (last >> 10) + ((last >> 10) < kRingChunks ? fr.warm_ops : 0));
+        const int rb = pos & (kRingBytes - 1);
+        if (rb + rbytes + 4 > kRingBytes) {                      // a dword may straddle the ring end: refresh the mirror
+            if (lane < kMirrorBytes / 16)
+                *reinterpret_cast<u32x4*>(fr.ring + kRingBytes + 16 * lane) =
+                    *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
+            wave_lds_sync();
+        }
+        uint32_t mark = 0, space = 0, amp = 0;
+        {
+            const int a0 = pos + (active ? sym : 0) * 2 * bf + 2 * ph0;
+            uint32_t qi = qi0;
+            int qp = qp0, ph = ph0;
+            for (int d = 0; d < pl / 2; d++) {
+                const uint32_t x = *reinterpret_cast<const u32_a2*>(fr.ring + ((a0 + 4 * d) & (kRingBytes - 1)));
+                uint32_t tm = 0, ts = 0;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    tm |= ((qi & 1u) ? 0x0000u : 0xFFFFu) << (16 * half);   // mark: hi on quarters 0, 2 (ref:80-85)
+                    ts |= (ph < h ? 0xFFFFu : 0x0000u) << (16 * half);      // space: hi on the first half (ref:68-77)
+                    ph++; qp++;
+                    if (qp == q) { qp = 0; qi++; }
+                }
+                const uint32_t lim = limit_pair_biased(x);                   // ref:344
+                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);              // ref:346
+                space = __builtin_amdgcn_sad_u16(lim, ts, space);            // ref:347
+                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);       // ref:94-98
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the round's reads have returned: refill
+        {
+            const int lim = ((pos + rbytes) >> 10) + kRingChunks;
+            while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
+        }
+        mark = group_sum_rt(mark, lps);
+        space = group_sum_rt(space, lps);
+        amp = group_sum_rt(amp, lps);
+        const int k0 = r * spp;
+        const uint32_t md = div_exact(mark, (uint32_t)bf, rcp_bf), sd = div_exact(space, (uint32_t)bf, rcp_bf);
+        const bool bit = active && md < sd;                                  // ref:348-351
+        if (margins && active && part == 0 && k0 + sym < mlim) margins[k0 + sym] = (int32_t)sd - (int32_t)md;
+        const int nv = (K - k0) < spp ? (K - k0) : spp;
+        const uint64_t bmask = compress_bits_rt(__ballot(bit), lps);
+        rxd_pass_rt(rd, bmask, nv, k0, spp, lane, words, out_row, out_stride, [&]() {
+            return compress_bits_rt(__ballot(active && amp >= amp_thr), lps);
+        });
+        if (rd.st.phase == 2) break;
+    }
+}
+
+template <int FLAGS>
+__device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, int bf, int32_t amp_end,
+                                                uint8_t* lds, int lane, RxState& st, uint8_t* out_row,
+                                                int out_stride, int& ci_out, int32_t& n_sym_out,
+                                                int32_t* margins, int32_t mstride, bool warm) {
+    FastRing fr;
+    fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
+    fr.ring = lds;
+    fr.lane = lane;
+#pragma unroll
+    for (int c = 0; c < kRingChunks; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
+    fr.next = kRingChunks;
+    if (warm) {
+#pragma unroll
+        for (int p = 0; p < kWarmOps; p++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(fr.rsrc, AFSK_LDS(lds + kWarmDummyOffset), 4, lane * 64,
+                                                     kRingBytes + 4096 * p, 0, 0);
+        fr.warm_ops = kWarmOps;
+    }
+    int ci = 0;
+    if constexpr (FLAGS & 1) fr.template wait_fixed<kRingChunks - 8>(7);
+    else ci = recover_clock_index_rt(fr, bf);
+    ci_out = ci;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // geometry: lanes per symbol, symbols per round
+    int lps = 2;
+    while (lps < 16 && bf % (4 * lps) == 0 && bf / lps > 64) lps *= 2;
+    int spp = 64 / lps;
+    while (spp > 1 && spp * 2 * bf > 8192) spp >>= 1;
+    const int32_t K = (len - ci - 1) / bf;                      // symbols with i < len - bf (ref:362,372)
+    n_sym_out = K;
+    const int32_t NR = (K + spp - 1) / spp;
+    const uint32_t amp_thr =
+        (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)bf;
+    const int byte0 = 2 * ci;
+    {
+        const int lim = (byte0 >> 10) + kRingChunks;            // chunks entirely below the clock index are free
+        while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
+    }
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
+    RxDeferred rd;
+    rxd_init(rd);
+    rt_rounds<FLAGS>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    rxd_finish<32>(rd, K, lane, words, out_row, out_stride);
+    st = rd.st;
+    wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
 template <int BF, int FLAGS>

@@ -584,26 +584,23 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
 #undef AFSK_FAST_CASE
             case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
             case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
-            default:  done = false; break;
+            default:            // every other valid bit_frames: the run-time geometry on the same ring
+                demod_stream_rt<FLAGS>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
+                                       margins, a.margin_stride, warm);
+                break;
         }
     }
-    if (!done) {            // two-pass path: every other valid bit_frames (and all of them in the v1 build)
+    if (!done) {            // FAST = false: the round-1 v1 two-pass design, kept for kbench A/B runs only
         if constexpr (!(FLAGS & kFlagSkipSync))
             ci = recover_clock_index(xs, len, bf, reinterpret_cast<int32_t*>(lds), lane);
         // phase B reuses the prefix-sum region: all LDS reads of phase A have returned
         // (their values were consumed), so the DMA writes below cannot overtake them.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (FAST) {
-            demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym,
-                                  margins, a.margin_stride);
-            if (st.npend >= 7) st.corrected += hamming_syndrome(st.pend & 127u) != 0;   // odd last codeword
-        } else {
-            switch (bf) {
-                case 40:  demod_symbols<40, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-                case 20:  demod_symbols<20, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-                case 160: demod_symbols<160, 4, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-                default:  demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
-            }
+        switch (bf) {
+            case 40:  demod_symbols<40, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+            case 20:  demod_symbols<20, 1, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+            case 160: demod_symbols<160, 4, FLAGS>(xs, len, ci, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
+            default:  demod_symbols_generic(xs, len, ci, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, n_sym); break;
         }
     }
     if (lane == 0) {

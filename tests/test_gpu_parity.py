@@ -747,6 +747,54 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
         assert np.array_equal(getattr(got2, f), getattr(got, f)[sub]), f
 
 
+def test_runtime_geometry_rates_vs_oracle(torch_cuda):
+    """Every valid bit_frames above 120 except 160 (375 baud and below) runs the single-pass ring
+    with a geometry computed at run time (lanes per symbol, symbols per round, run-time clock
+    recovery): clean, noisy and offset streams, soft outputs included, against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(808)
+    bauds = (375, 250, 240, 200, 160, 150, 125, 120, 100, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25, 24)
+    pieces, bfs, clean_payload = [], [], []
+    for baud in bauds:
+        bf = 48000 // baud
+        tx = afskmodem.Transmitter(baud, max(0.05, 24.0 / baud))
+        for k in range(6):
+            data = rng.integers(0, 256, 2 + (k % 3), dtype=np.uint8).tobytes()
+            w = tx.wav_samples(data)
+            lead = 0 if k == 0 else int(rng.integers(1, 4 * bf))
+            x = np.concatenate([rng.integers(-300, 300, lead).astype(np.int16), w])
+            if k == 3:
+                x = x[: len(x) - 4800]                       # no tail silence: last-symbol rule (i < len - bf)
+            if k >= 4:
+                x = np.clip(x.astype(np.int32) + rng.normal(0, 9000 if k == 4 else 20000, len(x)), -32768, 32767).astype(np.int16)
+            pieces.append(x); bfs.append(bf); clean_payload.append(data if k == 0 else None)
+        pieces.append(rng.integers(-32768, 32768, 9000).astype(np.int16)); bfs.append(bf); clean_payload.append(None)
+        pieces.append(np.zeros(5000, np.int16)); bfs.append(bf); clean_payload.append(None)
+    ln = np.array([len(p) for p in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    bf = np.array(bfs, np.int32)
+    flat = np.concatenate(pieces)
+    stride, ms = 64, 1024
+    want = O.demod_batch_soft(flat, off, ln, bf, 14000, out_stride=stride, margin_stride=ms)
+    got, corr, marg, nsym = soft_demod(torch, flat, off, ln, bf, 14000, stride, ms)
+    assert_same(got, want, "run-time geometry")
+    assert (nsym == want["n_symbols"]).all()
+    assert (corr == want["corrected"]).all()
+    col = np.arange(ms)[None, :]
+    mask = col < np.minimum(nsym, ms)[:, None]
+    bad = np.nonzero(((marg != want["margins"]) & mask).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    pl = got.payloads()
+    for i, data in enumerate(clean_payload):         # the clean, offset-free stream of every rate round-trips
+        if data is not None:
+            assert pl[i] == data, (i, int(bf[i]))
+    assert sum(n > 0 for n in got.nbytes) > len(pieces) // 2
+    for amp_end in (0, 22000):
+        g = device_demod(torch, flat, off, ln, bf, amp_end=amp_end, stride=stride)
+        w = O.demod_batch(flat, off, ln, bf, amp_end, out_stride=stride, n_threads=16)
+        assert_same(g, w, f"run-time geometry amp_end {amp_end}")
+
+
 def test_full_size_config3_mixed_baud_roundtrip(torch_cuda):
     """BASELINE config #3 at full size (65536 x 1 s, baud = {300,1200,2400} by stream index,
     6.3 GB): size-independent round trip (decoded == modulated payload for every stream) and
