@@ -4,7 +4,8 @@
 //   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks, several
 //                                                              symbols per lane
 //   60 / 96 / 100 / 120  (800 / 500 / 480 / 400 baud)          wm_rounds: rounds of any size, watermark refill
-// (anything else -- below 300 baud except 300 itself -- takes the two-pass path of afsk_demod_impl.h).
+// and every other valid bit_frames (128 and above: 375 baud and below, outside the documented range
+// but decodable by the reference's code) with a geometry computed at run time (rt_rounds).
 //
 // Every sample is fetched from HBM exactly once: the wave starts a 16 KiB LDS-DMA
 // ring at sample 0 the moment it starts, BEFORE the clock index is known, so the
@@ -1366,10 +1367,19 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp
     const int sym = lane / lps;                                  // symbol of the round this lane works on
     const bool active = sym < spp;
     const int32_t mlim = K < mstride ? K : mstride;
-    const float rcp_q = 1.0f / (float)q, rcp_bf = 1.0f / (float)bf;
+    const float rcp_bf = 1.0f / (float)bf;
+    constexpr uint32_t FULL = 65535u;
     const int ph0 = part * pl;                                   // phase of the piece's first sample
-    const uint32_t qi0 = div_exact((uint32_t)ph0, (uint32_t)q, rcp_q);
-    const int qp0 = ph0 - (int)qi0 * q;
+    // lps >= 4: a piece is (4 / lps) of a quarter symbol, so both templates are constant over it;
+    // lps == 2: a piece is two quarters -- mark template hi then lo (ref:80-85), split at sample q
+    // (inside a dword when q is odd), space template constant (ref:68-77).  Either way ONE v_sad_u16
+    // against "hi" per dword serves both correlators: SAD against lo = 65535 * n - SAD against hi.
+    const bool two_q = lps == 2;
+    const int quarter = two_q ? 0 : (part >> (__builtin_ctz((unsigned)lps) - 2));   // lps = 4, 8, 16 lanes: 1, 2, 4 per quarter
+    const bool mark_hi = (quarter & 1) == 0;                     // only used when !two_q
+    const bool space_hi = ph0 < h;
+    const int d_split = two_q ? (q >> 1) : (pl >> 1);            // dwords wholly in the first quarter
+    const bool odd_q = two_q && (q & 1);                         // dword d_split straddles the quarter boundary
     int pos = byte0;                                             // stream byte of the round's first sample
     for (int r = 0; r < NR; r++, pos += rbytes) {
         const int last = pos + rbytes + 3;                       // a 2-byte-aligned dword may reach 2 bytes further
@@ -1381,26 +1391,47 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp
                     *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
             wave_lds_sync();
         }
-        uint32_t mark = 0, space = 0, amp = 0;
+        uint32_t ha = 0, hb = 0, amp = 0;                        // SAD against "hi": first part / rest of the piece
         {
             const int a0 = pos + (active ? sym : 0) * 2 * bf + 2 * ph0;
-            uint32_t qi = qi0;
-            int qp = qp0, ph = ph0;
-            for (int d = 0; d < pl / 2; d++) {
-                const uint32_t x = *reinterpret_cast<const u32_a2*>(fr.ring + ((a0 + 4 * d) & (kRingBytes - 1)));
-                uint32_t tm = 0, ts = 0;
+            // dwords [d0, d1) of the piece into one accumulator; four reads are issued before their
+            // values are used, so the LDS latency is paid once per four dwords
+            auto accumulate = [&](uint32_t& hsum, int d0, int d1) {
+                int d = d0;
+                for (; d + 4 <= d1; d += 4) {
+                    uint32_t x[4];
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    tm |= ((qi & 1u) ? 0x0000u : 0xFFFFu) << (16 * half);   // mark: hi on quarters 0, 2 (ref:80-85)
-                    ts |= (ph < h ? 0xFFFFu : 0x0000u) << (16 * half);      // space: hi on the first half (ref:68-77)
-                    ph++; qp++;
-                    if (qp == q) { qp = 0; qi++; }
+                    for (int u = 0; u < 4; u++)
+                        x[u] = *reinterpret_cast<const u32_a2*>(fr.ring + ((a0 + 4 * (d + u)) & (kRingBytes - 1)));
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        hsum = __builtin_amdgcn_sad_u16(limit_pair_biased(x[u]), 0xFFFFFFFFu, hsum);   // ref:344, 346-347
+                        amp = __builtin_amdgcn_sad_u16(x[u] ^ kBias, kBias, amp);                      // ref:94-98
+                    }
                 }
-                const uint32_t lim = limit_pair_biased(x);                   // ref:344
-                mark = __builtin_amdgcn_sad_u16(lim, tm, mark);              // ref:346
-                space = __builtin_amdgcn_sad_u16(lim, ts, space);            // ref:347
-                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);       // ref:94-98
+                for (; d < d1; d++) {
+                    const uint32_t x = *reinterpret_cast<const u32_a2*>(fr.ring + ((a0 + 4 * d) & (kRingBytes - 1)));
+                    hsum = __builtin_amdgcn_sad_u16(limit_pair_biased(x), 0xFFFFFFFFu, hsum);
+                    amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);
+                }
+            };
+            accumulate(ha, 0, d_split);
+            int d = d_split;
+            if (odd_q) {                                         // sample q - 1 | sample q share this dword
+                const uint32_t x = *reinterpret_cast<const u32_a2*>(fr.ring + ((a0 + 4 * d) & (kRingBytes - 1)));
+                const uint32_t lim = limit_pair_biased(x);
+                ha += FULL - (lim & 0xFFFFu);
+                hb += FULL - (lim >> 16);
+                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);
+                d++;
             }
+            accumulate(hb, d, pl / 2);
+        }
+        uint32_t mark, space;
+        {
+            const uint32_t hall = ha + hb, fall = FULL * (uint32_t)pl;
+            mark = two_q ? ha + (FULL * (uint32_t)q - hb) : (mark_hi ? hall : fall - hall);
+            space = space_hi ? hall : fall - hall;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the round's reads have returned: refill
         {
@@ -1448,10 +1479,13 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // geometry: lanes per symbol, symbols per round
+    // lanes per symbol: pieces of at most 64 samples where the divisibility allows it, and a round of
+    // all 64 lanes no larger than 7.5 KiB (an 8 KiB round leaves too little of the ring in flight:
+    // 179 -> 9x us at bit_frames 128); then as many symbols per round as fit 7.5 KiB
     int lps = 2;
-    while (lps < 16 && bf % (4 * lps) == 0 && bf / lps > 64) lps *= 2;
+    while (lps < 16 && bf % (4 * lps) == 0 && (bf / lps > 64 || (64 / lps) * 2 * bf > 7680)) lps *= 2;
     int spp = 64 / lps;
-    while (spp > 1 && spp * 2 * bf > 8192) spp >>= 1;
+    while (spp > 1 && spp * 2 * bf > 7680) spp >>= 1;
     const int32_t K = (len - ci - 1) / bf;                      // symbols with i < len - bf (ref:362,372)
     n_sym_out = K;
     const int32_t NR = (K + spp - 1) / spp;

@@ -9,13 +9,14 @@
 // of ref:94-98, Hamming(7,4) decode ref:145-163 and MSB-first byte pack ref:393-399.
 //
 // Two implementations share this file's helpers:
-//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel for every bit_frames of the
-//     reference's documented 300 - 12000 baud range (4 ... 64, 60, 80, 96, 100, 120, 160; the list
-//     is the switch in process_stream); every sample is fetched from HBM exactly once.
-//   * the two-pass path below (recover_clock_index + demod_symbols*): a full 4096-entry prefix
-//     array for phase A, then a clock-index-aligned ring; used for the remaining valid
-//     bit_frames (below 300 baud: demod_symbols_generic) and, with FAST = false, as the round-1
-//     v1 kernel of the common bauds in kbench A/B runs.
+//   * afsk_demod_fast.h -- the single-pass LDS-DMA ring kernel, THE product path for every valid
+//     bit_frames: compile-time geometries for the reference's documented 300 - 12000 baud range
+//     (4 ... 64, 60, 80, 96, 100, 120, 160; the list is the switch in process_stream) and a
+//     run-time geometry for everything else (128 and above: 375 baud and below).  Every sample is
+//     fetched from HBM exactly once.
+//   * the two-pass design of round 1 below (recover_clock_index + demod_symbols*: a full
+//     4096-entry prefix array for phase A, then a clock-index-aligned ring): since round 2 only
+//     instantiated with FAST = false, i.e. as the "v1" baseline of tools/kbench.hip.
 //
 // No MFMA: this is an HBM-bound streaming reduction (2 B read per sample).
 // No workgroup barrier: the 4 waves of a block are independent streams.
@@ -536,8 +537,8 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 constexpr int kFlagOldSync = 8;     // bit_frames 20 / 40 / 80 / 160: prefix-window clock recovery instead of the lane-wise one
 // (FLAGS & 64: per-wave s_memrealtime stamps into DemodArgs::debug_stamps)
 
-// FAST = use the stream-aligned single-pass path (afsk_demod_fast.h) for every bit_frames it
-// covers (the switch in process_stream); the remaining valid values take the two-pass path.
+// FAST = the stream-aligned single-pass path (afsk_demod_fast.h) for every bit_frames -- the product;
+// FAST = false = the round-1 two-pass kernel (kbench baseline only).
 template <int FLAGS, bool FAST>
 struct KernelCfg {
     static constexpr int kLdsPerWave = FAST ? ((FLAGS & 8) ? kFastWaveLds : kFastWaveLdsProduct) : kWaveLds;
