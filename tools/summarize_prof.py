@@ -36,8 +36,8 @@ for f in find("prof_trace", "*kernel_trace.csv"):
         out["demod_kernel_trace"] = {"launches": len(d), "avg_ns": sum(d) / len(d),
                                      "median_ns": d[len(d) // 2], "min_ns": d[0], "max_ns": d[-1]}
         out["demod_kernel_resources"] = {k: rows[0].get(k) for k in
-                                         ("VGPR_Count", "SGPR_Count", "LDS_Block_Size",
-                                          "Workgroup_Size", "Grid_Size", "Scratch_Size")}
+                                         ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
+                                          "Workgroup_Size_X", "Grid_Size_X", "Scratch_Size")}
 for name, d in (("FETCH_SIZE", "prof_pmc1"), ("WRITE_SIZE", "prof_pmc2")):
     for f in find(d, "*counter_collection.csv"):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
@@ -64,7 +64,7 @@ if "hbm_bytes_per_launch" in out and wl in bench.WORKLOADS and wl != "custom":
         tj = {}
     if tj.get("kernel_source_hash") != out["kernel_source_hash"]:
         tj = {"kernel_source_hash": out["kernel_source_hash"], "entries": {}}
-    grid = int(out.get("demod_kernel_resources", {}).get("Grid_Size") or 0)
+    grid = int(out.get("demod_kernel_resources", {}).get("Grid_Size_X") or 0)
     tj["entries"][wl] = {"streams": grid // 64 if grid else bench.WORKLOADS[wl][0],
                          "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
                          "source": f"profiles/{os.environ.get('PROF_TAG', 'r2')}_{wl}_summary.json"}
