@@ -770,11 +770,16 @@ def test_runtime_geometry_rates_vs_oracle(torch_cuda):
             pieces.append(x); bfs.append(bf); clean_payload.append(data if k == 0 else None)
         pieces.append(rng.integers(-32768, 32768, 9000).astype(np.int16)); bfs.append(bf); clean_payload.append(None)
         pieces.append(np.zeros(5000, np.int16)); bfs.append(bf); clean_payload.append(None)
+        if baud in (375, 250, 200, 160, 100):
+            # long payloads: many ring laps and several deferred 64-byte Hamming flushes
+            data = rng.integers(0, 256, 150 + baud % 7, dtype=np.uint8).tobytes()
+            w = afskmodem.Transmitter(baud, 0.1).wav_samples(data)
+            pieces.append(np.concatenate([np.zeros(3, np.int16), w])); bfs.append(bf); clean_payload.append(data)
     ln = np.array([len(p) for p in pieces], np.int32)
     off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
     bf = np.array(bfs, np.int32)
     flat = np.concatenate(pieces)
-    stride, ms = 64, 1024
+    stride, ms = 192, 2400
     want = O.demod_batch_soft(flat, off, ln, bf, 14000, out_stride=stride, margin_stride=ms)
     got, corr, marg, nsym = soft_demod(torch, flat, off, ln, bf, 14000, stride, ms)
     assert_same(got, want, "run-time geometry")

@@ -11,7 +11,8 @@ rng = np.random.default_rng(5)
 bad = 0
 for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 2500, True), (3000, 2000, True), (2400, 1800, True),
                             (2000, 1500, True), (1500, 1200, True), (1000, 800, True), (750, 600, True), (600, 500, True), (300, 260, True),
-                            (800, 650, True), (500, 420, True), (480, 400, True), (400, 340, True)):
+                            (800, 650, True), (500, 420, True), (480, 400, True), (400, 340, True),
+                            (375, 320, True), (250, 220, True), (200, 170, True), (160, 130, True), (100, 90, True)):
     bf = 48000 // baud
     pieces = []
     for k in range(6):
