@@ -129,20 +129,46 @@ class Ctx:
         if self.world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
         _native.require_device()          # no GPU -> loud failure, never a CPU fallback
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # --share-gpu0 (diagnostic, with --dist-backend gloo): every rank uses device 0, so the whole
+        # N > 1 flow (launcher, ranks, gather, per-rank checks) can be exercised on a 1-GPU box;
+        # RCCL itself refuses two ranks on one device
+        dev_index = 0 if args.share_gpu0 else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
         self.use_dist = self.world > 1 or args.force_gather
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:
                 os.environ["MASTER_PORT"] = str(free_port())   # single-rank --force-gather only
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(args.dist_backend, rank=self.rank, world_size=self.world)
+        self.backend = args.dist_backend
         self.lib = _native.lib()
         self.cur = torch.cuda.current_stream()
         self.comm = torch.cuda.Stream(device=self.dev) if self.use_dist else None
 
     def t(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    def all_gather(self, out, inp) -> None:
+        """all_gather_into_tensor on device tensors (RCCL); the gloo diagnostic backend stages
+        through host memory."""
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(out, inp)
+            return
+        h_out = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(h_out, inp.cpu())
+        out.copy_(h_out)
+
+    def all_reduce(self, t, op=None) -> None:
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=op) if op is not None else self.dist.all_reduce(t)
+            return
+        h = t.cpu()
+        self.dist.all_reduce(h, op=op) if op is not None else self.dist.all_reduce(h)
+        t.copy_(h)
 
     def fence(self) -> None:
         self.torch.cuda.synchronize()
@@ -274,7 +300,7 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
             if state["timing"] and len(gather_timing) < 256:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record(comm)
-            dist.all_gather_into_tensor(gath_bufs[g & 1], out_all[gr * G * flat_sz: (gr + 1) * G * flat_sz])
+            ctx.all_gather(gath_bufs[g & 1], out_all[gr * G * flat_sz: (gr + 1) * G * flat_sz])
             if pair is not None:
                 pair[1].record(comm)
                 gather_timing.append(pair)
@@ -337,7 +363,7 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     kernel_ms = event_ms / max(steps, 1)           # avg launch duration incl. any gaps
     if ctx.use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ctx.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- which step gets the full check: a random one among those whose slot still holds it
@@ -395,7 +421,7 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
         gbuf = gath_bufs[g & 1]
         own = weighted_sum(torch, out_all[gr * G * flat_sz: (gr + 1) * G * flat_sz]).reshape(1)
         sums = torch.zeros(world, dtype=torch.int64, device=ctx.dev)
-        dist.all_gather_into_tensor(sums, own)
+        ctx.all_gather(sums, own)
         k_last = (steps - 1) % G
         per_rank = []
         for r in range(world):
@@ -414,9 +440,9 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
                 ok_pay = bool(same.all().item())
             per_rank.append(ok_sum and ok_pay is not False)
         mine = torch.tensor([int(all(per_rank))], dtype=torch.int32, device=ctx.dev)
-        dist.all_reduce(mine, op=dist.ReduceOp.MIN)
+        ctx.all_reduce(mine, op=dist.ReduceOp.MIN)
         ones = torch.ones(1, dtype=torch.int32, device=ctx.dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ctx.all_reduce(ones, op=dist.ReduceOp.SUM)
         rec["ranks_seen"] = int(ones.item())
         rec["gather_check"] = per_rank                       # rank 0's view: one entry per producer rank
         rec["gather_check_on_every_rank"] = bool(mine.item())
@@ -551,7 +577,9 @@ def run_rank(args) -> None:
         "data": "synthetic",
         "config": {"workload": sh.desc, "streams_per_gpu": sh.n_local, "streams_total": sh.n_total,
                    "stream_len": STREAM_LEN, "bauds": list(sh.bauds), "snr_db": sh.snr_db,
-                   "parallelism": f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")},
+                   "parallelism": f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")
+                                  + (" [DIAGNOSTIC: gloo backend" + (", all ranks on one GPU" if args.share_gpu0 else "") + "]"
+                                     if ctx.backend != "nccl" else "")},
         "value_event_time": rec["value_event_time"],
         "value_active_samples": rec["value_active_samples"],
         "roofline": rec["roofline"],
@@ -673,6 +701,10 @@ def main() -> None:
     ap.add_argument("--gather-every", type=int, default=0,
                     help="N > 1: all-gather the decoded records of G steps with one collective; "
                          "0 = as many steps as take about 4 ms (at most 64)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product); gloo = diagnostic, collectives staged through the host")
+    ap.add_argument("--share-gpu0", action="store_true",
+                    help="diagnostic: all ranks on device 0 (needs --dist-backend gloo), to exercise the N > 1 flow on a 1-GPU box")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
     args = ap.parse_args()
@@ -685,7 +717,10 @@ def main() -> None:
         # touches the GPU in this process (device_count() does not initialise it on this image).
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if args.share_gpu0 and args.dist_backend != "gloo":
+            sys.stderr.write("bench.py: --share-gpu0 needs --dist-backend gloo (RCCL refuses two ranks on one device)\n")
+            raise SystemExit(2)
+        if have < (1 if args.share_gpu0 else args.gpus):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible\n")
             raise SystemExit(2)
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))

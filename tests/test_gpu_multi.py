@@ -152,3 +152,26 @@ def test_host_entries_follow_the_current_device():
         if want is None:
             want = got
         assert got.payloads() == want.payloads() and one.payloads()[0] == want.payloads()[0], dev
+
+
+def test_bench_two_rank_flow_on_one_gpu():
+    """`python bench.py --gpus 2` end to end from a bare interpreter on a 1-GPU box: the parent
+    launches two ranks (torch.distributed.run) without touching the GPU, both ranks demodulate
+    their shard on device 0, exchange the decoded records (diagnostic gloo backend: RCCL refuses two
+    ranks on one device) and every rank verifies every rank's gathered slice; ONE JSON line, rc 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--share-gpu0", "--workload", "config2", "--streams", "768", "--sub", "", "--steps", "9",
+                        "--warmup", "2", "--preroll-ms", "0", "--gather-every", "4"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["gather_check"] == [True, True] and d["gather_check_on_every_rank"] is True
+    assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
+    assert d["config"]["streams_total"] == 1536 and d["gathers_in_timed_region"] == 3
