@@ -311,27 +311,46 @@ int wav_probe_one(const char* path, int64_t* data_off, int64_t* data_bytes) {
     *data_off = 0; *data_bytes = 0;
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return AFSK_WAV_IO;
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); return AFSK_WAV_IO; }
-    const int64_t fsize = (int64_t)st.st_size;
-    unsigned char h[24];
+    // ONE read covers the RIFF header and the chunk headers of nearly every file (44-byte header,
+    // perhaps a LIST chunk); chunk headers beyond it are read one by one.  The file size comes from
+    // a short read or, for longer files, from fstat.
+    constexpr int64_t kHead = 512;
+    unsigned char head[kHead];
+    int64_t have = 0;
+    for (;;) {
+        const ssize_t r = pread(fd, head + have, (size_t)(kHead - have), (off_t)have);
+        if (r < 0) { close(fd); return AFSK_WAV_IO; }
+        if (r == 0) break;
+        have += r;
+        if (have == kHead) break;
+    }
+    int64_t fsize = have;
+    if (have == kHead) {
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return AFSK_WAV_IO; }
+        fsize = (int64_t)st.st_size;
+    }
+    auto fetch = [&](int64_t off, int n, unsigned char* dst) {      // n bytes at off, from the buffer when possible
+        if (off + n <= have) { std::memcpy(dst, head + off, (size_t)n); return true; }
+        return pread_all(fd, dst, (size_t)n, off);
+    };
+    unsigned char h[16];
     int rc = AFSK_WAV_NO_DATA;
-    if (fsize < 12 || !pread_all(fd, h, 12, 0) || std::memcmp(h, "RIFF", 4) != 0 ||
-        std::memcmp(h + 8, "WAVE", 4) != 0) {
+    if (fsize < 12 || std::memcmp(head, "RIFF", 4) != 0 || std::memcmp(head + 8, "WAVE", 4) != 0) {
         close(fd);
         return AFSK_WAV_NOT_RIFF;
     }
     // chunks inside the RIFF form end where the RIFF size says (Chunk.read clips to it), or at EOF
-    const int64_t form_end = std::min<int64_t>(fsize, 8 + (int64_t)le32(h + 4));
+    const int64_t form_end = std::min<int64_t>(fsize, 8 + (int64_t)le32(head + 4));
     int64_t pos = 12;
     int64_t framesize = 0;
     while (pos + 8 <= form_end) {
-        if (!pread_all(fd, h, 8, pos)) { rc = AFSK_WAV_IO; break; }
+        if (!fetch(pos, 8, h)) { rc = AFSK_WAV_IO; break; }
         const int64_t csize = (int64_t)le32(h + 4);
         const int64_t body = pos + 8;
         if (std::memcmp(h, "fmt ", 4) == 0) {
-            const int64_t have = std::min<int64_t>(csize, form_end - body);
-            if (have < 16 || !pread_all(fd, h, 16, body)) { rc = AFSK_WAV_FORMAT; break; }
+            const int64_t avail = std::min<int64_t>(csize, form_end - body);
+            if (avail < 16 || !fetch(body, 16, h)) { rc = AFSK_WAV_FORMAT; break; }
             const uint32_t tag = le16(h), channels = le16(h + 2), bits = le16(h + 14);
             const uint32_t width = (bits + 7) / 8;
             if (tag != 1 || channels == 0 || width == 0) { rc = AFSK_WAV_FORMAT; break; }
