@@ -800,6 +800,41 @@ def test_runtime_geometry_rates_vs_oracle(torch_cuda):
         assert_same(g, w, f"run-time geometry amp_end {amp_end}")
 
 
+def test_every_bit_frames_value_the_kernel_accepts(torch_cuda):
+    """The device entry takes bit_frames as a device array and accepts every multiple of 4 with
+    2 * bf < 4096 (host wrappers additionally require 48000 % bf == 0, like the reference): ALL 511
+    values, 4 ... 2044 -- the compile-time geometries and, for everything else, the run-time one --
+    on a clean stream and a noisy one each, against the oracle (which is a literal scalar loop for
+    any bf)."""
+    torch = torch_cuda
+    dev = "cuda:0"
+    rng = np.random.default_rng(4044)
+    bfs = np.arange(4, 2048, 4, dtype=np.int32)
+    n = 2 * len(bfs)
+    bf = np.repeat(bfs, 2)
+    ts = np.where(bf <= 64, 60, np.where(bf <= 320, 12, 4)).astype(np.int32)
+    plen = np.full(n, 2, np.int32)
+    payload = rng.integers(0, 256, (n, 2), dtype=np.uint8)
+    ln = (ts * 2 * bf + 4 * bf + 28 * bf + 4800).astype(np.int32)
+    ln = np.maximum(ln, 4200).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    total = int(off[-1] + ln[-1])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x = torch.zeros(total, dtype=torch.int16, device=dev)
+    d_off, d_ln, d_bf = t(off), t(ln), t(bf)
+    batch.modulate_batch(t(payload), t(plen), d_bf, t(ts), d_off, d_ln, int(ln.max()), x, False)
+    q = np.where(np.arange(n) % 2 == 0, synth.snr_to_scale_q24(60.0), synth.snr_to_scale_q24(8.0)).astype(np.int32)
+    batch.add_noise_batch(x, d_off, d_ln, int(ln.max()), q, seed=77)
+    stride = 16
+    res = batch.demod_batch(x, d_off, d_ln, d_bf, 14000, out_stride=stride, validate=False)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    want = O.demod_batch(x.cpu().numpy(), off, ln, bf, 14000, out_stride=stride, n_threads=16)
+    assert_same(got, want, "every bit_frames")
+    ok = sum(got.payloads()[i] == payload[i].tobytes() for i in range(0, n, 2))
+    assert ok > 0.9 * len(bfs), ok        # the clean stream of (nearly) every width round-trips
+
+
 def test_full_size_config3_mixed_baud_roundtrip(torch_cuda):
     """BASELINE config #3 at full size (65536 x 1 s, baud = {300,1200,2400} by stream index,
     6.3 GB): size-independent round trip (decoded == modulated payload for every stream) and
