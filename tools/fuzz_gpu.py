@@ -20,12 +20,13 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
 total_bad = 0
-for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400, 200):
+for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400, 375, 250, 240, 200,
+             160, 150, 125, 120, 100, 96, 75, 50, 32, 24):
     bf = 48000 // baud
     burst = O.wav_convert(O.get_frames(bytes(rng.integers(0, 256, 3, dtype=np.uint8)), baud, 0.03))
     pieces = []
     for i in range(n):
-        L = int(rng.integers(4096, 7000))
+        L = int(rng.integers(4096, 7000 if bf <= 160 else 7000 + 12 * bf))
         kind = i % 4
         if kind == 0:
             x = rng.integers(-32768, 32768, L).astype(np.int16)
@@ -70,7 +71,7 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
         total_bad += bad
         if amp_end == 14000:          # soft outputs (afsk_demod_batch_ex) on a slice of the batch
             m = min(400, len(pieces))
-            ms = 7000 // bf + 1
+            ms = int(ln.max()) // bf + 1
             soft = O.demod_batch_soft(flat, off[:m], ln[:m], bfa[:m], amp_end, out_stride=64, margin_stride=ms)
             r2 = batch.demod_batch(x, torch.from_numpy(off[:m]).cuda(), torch.from_numpy(ln[:m]).cuda(), bfa[:m],
                                    amp_end, out_stride=64, diagnostics=True, margin_stride=ms)
