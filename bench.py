@@ -163,11 +163,12 @@ class Ctx:
         out.copy_(h_out)
 
     def all_reduce(self, t, op=None) -> None:
+        kw = {} if op is None else {"op": op}
         if self.backend == "nccl":
-            self.dist.all_reduce(t, op=op) if op is not None else self.dist.all_reduce(t)
+            self.dist.all_reduce(t, **kw)
             return
         h = t.cpu()
-        self.dist.all_reduce(h, op=op) if op is not None else self.dist.all_reduce(h)
+        self.dist.all_reduce(h, **kw)
         t.copy_(h)
 
     def fence(self) -> None:
