@@ -357,6 +357,31 @@ def main():
             add_case(f"garbage/{baud}/{total}/{scale}", x.tolist(), baud, amp_end=amp_end,
                      gen={"kind": "garbage", "total": total, "seed": 4242, "stream_idx": baud + total,
                           "scale_q24": scale})
+    # appended in round 2 (fresh generator again): every other baud rate the reference can round-trip
+    #  -- the rates that got their own single-pass geometry (800 / 500 / 480 / 400, the
+    # several-symbols-per-lane group) and three below 300 baud (run-time geometry) -- clean, with a
+    # leading offset, noisy, and one garbage stream each
+    rng4 = np.random.default_rng(20261003)
+    for baud in (800, 500, 480, 400, 750, 1000, 1500, 2000, 3000, 4000, 6000, 200, 150, 100):
+        data = rng4.integers(0, 256, 6, dtype=np.uint8).tobytes()
+        tt = 0.25 if baud >= 400 else 0.5
+        w = wav_frames(data, baud, tt)
+        add_case(f"r2/clean/{baud}", w.tolist(), baud,
+                 gen={"kind": "wav", "payload_hex": data.hex(), "baud": baud, "training_time": tt, "total": None})
+        lead = int(rng4.integers(1, 3 * (48000 // baud)))
+        wl = np.concatenate([np.zeros(lead, np.int16), w])
+        add_case(f"r2/lead{lead}/{baud}", wl.tolist(), baud,
+                 gen={"kind": "wav_lead", "payload_hex": data.hex(), "baud": baud, "training_time": tt, "lead": lead})
+        for snr in (9, 4):
+            q = snr_to_scale_q24(snr)
+            noisy = O.add_noise(w, seed=79, stream_idx=baud + snr, scale_q24=q)
+            add_case(f"r2/noise/{baud}/snr{snr}", noisy.tolist(), baud,
+                     gen={"kind": "wav_noise", "payload_hex": data.hex(), "baud": baud, "training_time": tt,
+                          "total": len(w), "seed": 79, "stream_idx": baud + snr, "scale_q24": q, "snr_db": snr})
+        total = 6000 + 10 * (48000 // baud)
+        x = O.add_noise(np.zeros(total, np.int16), seed=4343, stream_idx=baud, scale_q24=1 << 22)
+        add_case(f"r2/garbage/{baud}", x.tolist(), baud,
+                 gen={"kind": "garbage", "total": total, "seed": 4343, "stream_idx": baud, "scale_q24": 1 << 22})
     G["decode_cases"] = cases
 
     # ---- 5b. live gate (Receiver.__listen ref:299-319) replayed over finite captures
