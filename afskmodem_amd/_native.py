@@ -20,6 +20,7 @@ WAV_OK = 0
 
 SAMPLE_RATE = 48000
 SYNC_WINDOW = 4096
+MAX_STREAM_LEN = (1 << 30) - (1 << 15)      # AFSK_MAX_STREAM_LEN: 32-bit byte offsets in the kernels
 
 
 class AfskNativeError(RuntimeError):

@@ -395,8 +395,8 @@ def load_wav_batch(filenames, device="cuda:0"):
         odd[int(i)] = read_wav_frames(names[int(i)])     # raises what the reference raises
         d_bytes[i] = 2 * len(odd[int(i)])
     lens = (d_bytes // 2).astype(np.int64)
-    if int(lens.max()) >= (1 << 30):
-        raise ValueError("a stream of 2^30 samples or more")
+    if int(lens.max()) > _native.MAX_STREAM_LEN:
+        raise ValueError("a stream longer than AFSK_MAX_STREAM_LEN samples")
     padded = (lens + 7) & ~np.int64(7)               # every stream starts on a 16-byte boundary
     offs = np.zeros(n, np.int64)
     offs[1:] = np.cumsum(padded[:-1])

@@ -476,9 +476,9 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
         const int bf = bit_frames[s];
         if (bf < 4 || (bf & 3) || 2 * bf >= AFSK_SYNC_WINDOW)
             return fail(AFSK_E_INVALID_BAUD, "bit_frames must be a multiple of 4 with 2*bf < 4096");
-        if (stream_len[s] < 0 || stream_len[s] >= (1 << 30) || stream_offset[s] < 0 ||
+        if (stream_len[s] < 0 || stream_len[s] > AFSK_MAX_STREAM_LEN || stream_offset[s] < 0 ||
             stream_offset[s] + stream_len[s] > total_samples)
-            return fail(AFSK_E_INVALID_ARG, "stream outside the sample buffer (or 2^30 samples and longer)");
+            return fail(AFSK_E_INVALID_ARG, "stream outside the sample buffer (or longer than AFSK_MAX_STREAM_LEN)");
     }
     if (int rc0 = require_device()) return rc0;
 
@@ -584,7 +584,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
         const int bf = bit_frames[s];
         if (bf < 4 || (bf & 3) || 2 * bf >= AFSK_SYNC_WINDOW)
             return fail(AFSK_E_INVALID_BAUD, "bit_frames must be a multiple of 4 with 2*bf < 4096");
-        if (stream_len[s] < 0 || stream_len[s] >= (1 << 30) || (stream_len[s] > 0 && !streams[s]))
+        if (stream_len[s] < 0 || stream_len[s] > AFSK_MAX_STREAM_LEN || (stream_len[s] > 0 && !streams[s]))
             return fail(AFSK_E_INVALID_ARG, "bad stream length or null stream pointer");
         h_off[s] = total_samples;
         total_samples += ((int64_t)stream_len[s] + 7) & ~(int64_t)7;

@@ -50,6 +50,8 @@ extern "C" {
 #define AFSK_SYNC_WINDOW 4096  /* :323,327                */
 #define AFSK_DEAD_ZONE 512     /* :290-292                */
 #define AFSK_TAIL_SILENCE 4800 /* :468                    */
+/* Longest stream the kernels address with 32-bit byte offsets (about 6.2 hours of audio). */
+#define AFSK_MAX_STREAM_LEN ((1 << 30) - (1 << 15))
 
 int afsk_version(void);
 /* Copies the calling thread's last error message (NUL terminated, truncated to
@@ -66,7 +68,7 @@ int afsk_sync(void *hip_stream);
  *
  *  samples        int16 mono 48 kHz, all streams in one allocation
  *  stream_offset  [n] first sample of stream s, in samples from `samples`
- *  stream_len     [n] length of stream s in samples (>= 0, < 2^30)
+ *  stream_len     [n] length of stream s in samples (0 ... AFSK_MAX_STREAM_LEN)
  *  bit_frames     [n] 48000 / baud of stream s (Receiver.__init__ :277);
  *                 must be a multiple of 4 with 2*bit_frames < 4096
  *  amp_end_threshold  Receiver(amp_end_threshold=...) (:276), squelch of :375
@@ -118,7 +120,7 @@ int afsk_demod_batch_ex(const int16_t *samples, const int64_t *stream_offset,
  * Both host entries work on a private NON-BLOCKING HIP stream of the calling thread (never the
  * NULL stream): they do not synchronise with the caller's own streams or with calls made by
  * other threads, and may be called concurrently (the reference's Receivers are independent
- * objects, afskmodem.py:275-284).  stream_len[s] must be < 2^30 here as well.
+ * objects, afskmodem.py:275-284).  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
  */
 int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           const int64_t *stream_offset, const int32_t *stream_len,
