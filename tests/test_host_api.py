@@ -207,6 +207,17 @@ def test_cabi_argument_checks_new_entries():
     neg = np.array([-1], np.int32)
     assert lib.afsk_demod_streams_host(ptrs, p(neg, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
                                        *outs) == _native.E_INVALID_ARG
+    too_long = np.array([_native.MAX_STREAM_LEN + 1], np.int32)     # byte offsets would leave int32
+    assert lib.afsk_demod_streams_host(ptrs, p(too_long, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
+                                       *outs) == _native.E_INVALID_ARG
+    off0 = np.zeros(1, np.int64)
+    assert lib.afsk_demod_batch_host(p(x, ctypes.c_int16), 1 << 31, p(off0, ctypes.c_int64), p(too_long, ctypes.c_int32),
+                                     p(bf, ctypes.c_int32), 14000, 1, *outs) == _native.E_INVALID_ARG
+    # the new file-ingest entries
+    assert lib.afsk_wav_probe(None, -1, None, None, None) == _native.E_INVALID_ARG
+    assert lib.afsk_wav_probe(None, 0, None, None, None) == 0
+    assert lib.afsk_wav_upload(None, None, None, None, 0, None, 0) == 0
+    assert lib.afsk_wav_upload(None, None, None, None, 3, None, 10) == _native.E_INVALID_ARG
     null = (ctypes.c_void_p * 1)(None)
     assert lib.afsk_demod_streams_host(null, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
                                        *outs) == _native.E_INVALID_ARG
