@@ -668,6 +668,9 @@ def run_rank(args) -> None:
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
+    out["scaling_note"] = ("headline workload: config2 (4096 streams/GPU) at N = 1, config5 (65536 streams/GPU, the shard "
+                           "north_star names) at N > 1; every line carries both in per_workload_value, so each "
+                           "weak-scaling curve has its own 1-GPU point (config5's is per_workload_value.config5 of the N = 1 line)")
     if ctx.use_dist:
         dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit,
