@@ -966,6 +966,34 @@ def test_fuzz_noise_streams_every_rate(torch_cuda):
             assert_same(got, want, f"fuzz baud {baud} amp_end {amp_end}")
 
 
+def test_kernel_time_sanity(torch_cuda):
+    """Not a benchmark (bench.py is): a loose guard against gross regressions -- a geometry that
+    silently falls off the single-pass ring, register spills, a lost prefetch.  4096 x 1 s streams
+    per rate; bounds are ~1.6x what the r2 kernel needs on the slowest box seen (62-73 us for the
+    documented range, 80-112 us for the run-time geometry)."""
+    torch = torch_cuda
+    limits = {1200: 100.0, 300: 105.0, 2400: 105.0, 480: 110.0, 800: 110.0, 6000: 110.0, 12000: 120.0,
+              250: 160.0, 100: 150.0}
+    for baud, limit_us in limits.items():
+        b = synth_batch(torch, 4096, (baud,), seed=5, payload_len=synth.one_second_payload(baud),
+                        wav_quirk=baud != 12000)
+        stride = batch.out_stride_for(48000, 48000 // baud)
+        out = batch.alloc_result(4096, stride, "cuda:0")
+        for _ in range(30):
+            batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out=out, validate=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out=out, validate=False)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        assert us < limit_us, f"{baud} baud: {us:.1f} us per 4096 x 1 s launch (limit {limit_us})"
+        got = out.cpu()
+        assert (got.nbytes == synth.one_second_payload(baud)).all()
+
+
 def test_max_size_config5_on_one_gpu(torch_cuda):
     """BASELINE config #5's whole stream count (524288 x 1 s @1200 baud = 50 GB, normally
     sharded over 8 GPUs) on ONE MI355X: every stream decodes to its payload, and a
