@@ -36,6 +36,15 @@ namespace afsk {
 
 constexpr int kRingBytes = 16384;
 constexpr int kRingChunks = 16;
+// LDS of a wave behind the ring
+constexpr int kMirrorBytes = 256;                              // copy of ring bytes 0..255 right behind the ring: a lane's
+                                                               // piece may run linearly past the ring end (wm_rounds)
+constexpr int kBitBufOffset = kRingBytes + kMirrorBytes;       // phase C's 64-word bit buffer behind the mirror
+constexpr int kBitBufBytes = 512;
+constexpr int kWarmDummyOffset = kBitBufOffset + kBitBufBytes;  // 256 bytes the warming requests may scribble on
+constexpr int kProbeOffset = kWarmDummyOffset + 256;            // 64 dwords: the tail-hint probes land here
+constexpr int kHintStashOffset = kProbeOffset + 256;            // 16 bytes: probe spacing, parked here instead of in scalar registers
+
 // L2 warming behind the ring start (r2).  While a wave computes phase A its 16 ring chunks have
 // landed and it has nothing in flight -- LDS caps the ring at 16 KiB.  Right behind the 16 chunk
 // requests the wave therefore asks for one dword of every 64 bytes of stream bytes 16 KiB .. 24 KiB
@@ -47,6 +56,18 @@ constexpr int kRingChunks = 16;
 // every line is then requested twice and the request path, not HBM, becomes the limit.
 constexpr int kWarmOps = 2;
 constexpr int kWarmMinStreams = 8192;
+// Tail hint (r2, armed together with the warming, i.e. for launches of kWarmMinStreams or more).
+// A stream ends in silence (4800 zero samples behind every Transmitter frame, ref:468) that the
+// reference never reads -- it stops at the first quiet symbol -- but a prefetching reader requests it
+// long before it can know: ~10 KiB are in flight when the squelch fires, i.e. the whole 9.6 KB tail.
+// So, once phase A is done, the wave requests kProbes single dwords, each the last dword of a round
+// (of every m-th round, so that kProbes of them cover the stream; one LDS-DMA instruction, 2 KiB of
+// HBM traffic), and when they have landed it looks for the LAST probe that is loud by the squelch's
+// own measure (|x0| + |x1| >= 2 * amp_end): the signal then ends inside the round group closed by the
+// next probe, and chunks behind that group are not requested AHEAD OF NEED any more.  This is a prefetch policy only: a round that needs a chunk which was held back requests it
+// on the spot (and drops the hint), so results cannot change -- e.g. a weak signal below amp_end
+// with no loud probe at all still decodes, one demand fetch later.
+constexpr int kProbes = 32;
 
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
@@ -67,6 +88,80 @@ struct FastRing {
     __device__ __forceinline__ void issue(int c) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + (c & (kRingChunks - 1)) * 1024),
                                                  16, lane * 16, c * 1024, 0, AUX);
+    }
+
+    // ---- tail hint (see kProbes) ----  (state kept small: the round loops are short of scalar registers)
+    int hint_state = 0;            // bit 0: probes requested for this stream, bit 1: evaluated, bit 2: the hint is
+                                   // holding chunks back (round loops with a fixed schedule switch to the
+                                   // dynamic one), bits 3..: misses
+    int hint_lim = 0x7fffffff;     // chunks at or above this index are not requested ahead of need
+
+    __device__ __forceinline__ bool hint_armed() const { return (hint_state & 1) != 0; }
+    __device__ __forceinline__ bool hint_holding() const { return (hint_state & 4) != 0; }
+    // a loop that requests a fixed number of chunks per round calls this before doing so: true (and
+    // sticky) once that request would cross the hint
+    __device__ __forceinline__ bool hint_takes_over(int chunks_per_round) {
+        if (next + chunks_per_round > hint_lim) hint_state |= 4;
+        return (hint_state & 4) != 0;
+    }
+
+    // Requested after phase A and before chunk 16, so the probes do not compete with the wave's first
+    // 16 KiB and count like the warming requests ("between chunk 15 and chunk 16") in the waits.
+    // Probe j is the last dword below stream byte base + (j + 1) * step, step = m rounds with m chosen
+    // so that kProbes of them cover the stream: a probe sits at the END OF A ROUND, and if it is quiet
+    // and the one before it loud, the signal ends inside the rounds between them and the last chunk the
+    // decoder can need is the one holding that very dword.
+    __device__ __forceinline__ void request_probes(uint32_t stream_bytes, int base, int round_bytes) {
+        const uint32_t span = stream_bytes > (uint32_t)base ? stream_bytes - (uint32_t)base : 0u;
+        const uint32_t rounds = span / (uint32_t)round_bytes + 1u;
+        const int step = (int)(((rounds + kProbes - 1) / kProbes) * (uint32_t)round_bytes);
+        if (lane == 0) *reinterpret_cast<int*>(ring + kHintStashOffset) = step;
+        const uint32_t po = (uint32_t)base + (uint32_t)((lane & (kProbes - 1)) + 1) * (uint32_t)step;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + kProbeOffset), 4, (int)(po - 4u), 0, 0, 0);
+        warm_ops += 1;
+        hint_state = 1;
+    }
+    // chunk `need` has landed (dynamic form of wait_fixed: the number of requests behind it varies
+    // once chunks are held back)
+    __device__ __forceinline__ void wait_landed(int need) {
+        wait_vmcnt_dyn(next - 1 - need + (need < kRingChunks ? warm_ops : 0));
+    }
+    // a round needs chunk `need`: request whatever of it was held back.  One such miss is normal (noise
+    // can push the stop one symbol into the next round); a second one means the hint is wrong: drop it.
+    template <int AUX>
+    __device__ __forceinline__ void fetch_through(int need) {
+        if (next > need) return;
+        hint_state += 8;
+        hint_lim = hint_state >= 16 ? 0x7fffffff : need + 1;
+        while (next <= need) {
+            issue<AUX>(next);
+            next++;
+        }
+    }
+    // request every chunk below lim (that the hint allows)
+    template <int AUX, bool HINTED = true>
+    __device__ __forceinline__ void top_up(int lim) {
+        if constexpr (HINTED) lim = lim < hint_lim ? lim : hint_lim;
+        while (next < lim) {
+            issue<AUX>(next);
+            next++;
+        }
+    }
+    // once a chunk >= 16 has landed the probes have too: hold back everything behind the round group
+    // whose closing probe is the first quiet one after the last loud one (amp1 = the squelch threshold
+    // per sample, 0 = nothing is ever quiet; base as given to request_probes; extra = bytes a round
+    // reads past its end when re-aligning)
+    __device__ __forceinline__ void eval_probes(int need, uint32_t amp1, int base, int extra) {
+        if ((hint_state & 2) || need < kRingChunks) return;
+        hint_state |= 2;
+        wave_lds_sync();
+        const int step = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset));
+        const uint32_t pv = *reinterpret_cast<const uint32_t*>(ring + kProbeOffset + 4 * lane);
+        const uint32_t a2 = __builtin_amdgcn_sad_u16(pv ^ kBias, kBias, 0u);               // |x0| + |x1|
+        const uint32_t mask = (uint32_t)__ballot(a2 >= 2u * amp1) & (uint32_t)((1ull << kProbes) - 1ull);
+        if (amp1 == 0 || (mask >> (kProbes - 1))) return;                                  // loud to the very end
+        const int q = mask ? 32 - __builtin_clz(mask) : 0;                                 // first probe of the quiet tail
+        hint_lim = ((base + (q + 1) * step - 1 + extra) >> 10) + 1;
     }
 };
 
@@ -125,13 +220,8 @@ constexpr int kWinExtraBytes = 2560;                           // own-LDS window
 static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
               "window LDS too small");
 constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave with the prefix window (FLAGS & 8)
-constexpr int kMirrorBytes = 256;                              // copy of ring bytes 0..255 right behind the ring: a lane's
-                                                               // piece may run linearly past the ring end (wm_rounds)
-constexpr int kBitBufOffset = kRingBytes + kMirrorBytes;       // phase C's 64-word bit buffer behind the mirror
-constexpr int kBitBufBytes = 512;
-constexpr int kWarmDummyOffset = kBitBufOffset + kBitBufBytes;  // 256 bytes the warming requests may scribble on
-constexpr int kFastWaveLdsProduct = kWarmDummyOffset + 256;     // 17 KiB per wave: what the product build needs
-static_assert(kWarmDummyOffset + 256 <= kFastWaveLds, "bit buffer / dummy area outside the diagnostic build's LDS");
+constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 17.27 KiB per wave: what the product build needs
+static_assert(kHintStashOffset + 16 <= kFastWaveLds, "bit buffer / dummy / probe areas outside the diagnostic build's LDS");
 
 template <int BF, bool DEBUG = false>
 __device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
@@ -840,7 +930,7 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
 // The round loop.  ALIGNED = the wave-uniform shift (2*ci) & 15 is zero (always true for
 // Transmitter-generated streams, whose clock index is a multiple of the training period):
 // five aligned ds_read_b128 feed the arithmetic directly.  Otherwise six reads + v_alignbyte.
-template <int BF, int FLAGS, bool ALIGNED>
+template <int BF, int FLAGS, bool ALIGNED, bool HINTED>
 __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                             uint32_t amp_thr, RxDeferred& rd,
                                             unsigned long long* words, uint8_t* out_row,
@@ -852,7 +942,14 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
         // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
         // 10 youngest DMAs may still be in flight.
-        fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
+        if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed 5-chunks-per-round schedule
+            const int need = (byte0 + 5120 * r + 5119 + (ALIGNED ? 0 : 16)) >> 10;     // chunk of the last byte read
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(need);
+            fr.wait_landed(need);
+        } else {
+            fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
+            if constexpr (HINTED) fr.eval_probes(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : 16);
+        }
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
         if constexpr (BF == 20) {
@@ -923,9 +1020,13 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         // the reads above have returned (their values are in x): refill the 5 chunks this
         // round consumed right away, before the arithmetic
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (HINTED && fr.hint_takes_over(5)) {
+            fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 5120 * (r + 1)) >> 10) + kRingChunks);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
-        fr.next += 5;
+            for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+            fr.next += 5;
+        }
         fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, rd, words, out_row, out_stride,
                                       margins, mstride);
         if (rd.st.phase == 2) break;
@@ -952,7 +1053,7 @@ struct MultiGeom {
     static_assert(!valid || (SPL * BF == 8 * R && PB % RW == 0 && R + 1 < kRingChunks), "round geometry");
 };
 
-template <int BF, int FLAGS, bool ALIGNED>
+template <int BF, int FLAGS, bool ALIGNED, bool HINTED>
 __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                              uint32_t amp_thr, RxDeferred& rd,
                                              unsigned long long* words, uint8_t* out_row,
@@ -968,7 +1069,14 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
     for (int r = 0; r < NR; r++) {
         // bytes [byte0 + 1024 R r, +1024 R) must have landed: at most R + 1 chunks from the oldest
         // resident one; chunks through B_r + 15 are issued, so the 15 - R youngest may be in flight
-        fr.template wait_fixed<kRingChunks - 1 - R>(((byte0 + 1024 * R * r) >> 10) + R);
+        if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed R-chunks-per-round schedule
+            const int need = (byte0 + 1024 * R * (r + 1) - 1 + (ALIGNED ? 0 : RW)) >> 10;   // chunk of the last byte read
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(need);
+            fr.wait_landed(need);
+        } else {
+            fr.template wait_fixed<kRingChunks - 1 - R>(((byte0 + 1024 * R * r) >> 10) + R);
+            if constexpr (HINTED) fr.eval_probes(((byte0 + 1024 * R * r) >> 10) + R, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : RW);
+        }
         uint32_t x[SPL * NO];
         const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
 #pragma unroll
@@ -1022,9 +1130,13 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill right away
+        if (HINTED && fr.hint_takes_over(R)) {
+            fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 1024 * R * (r + 1)) >> 10) + kRingChunks);
+        } else {
 #pragma unroll
-        for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
-        fr.next += R;
+            for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+            fr.next += R;
+        }
 
         const int k0 = r * SPR;
         uint64_t B[SPL];
@@ -1100,7 +1212,7 @@ struct WmGeom {
                   "round geometry");
 };
 
-template <int BF, int FLAGS, bool ALIGNED>
+template <int BF, int FLAGS, bool ALIGNED, bool HINTED>
 __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                           uint32_t amp_thr, RxDeferred& rd,
                                           unsigned long long* words, uint8_t* out_row,
@@ -1119,8 +1231,9 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
-        wait_vmcnt_dyn(fr.next - 1 - (last >> 10) +               // chunks through last >> 10 have landed
-                       ((last >> 10) < kRingChunks ? fr.warm_ops : 0));
+        if constexpr (HINTED) fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);   // a held-back chunk
+        fr.wait_landed(last >> 10);                               // chunks through last >> 10 have landed
+        if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0 & ~(RW - 1), EXTRA);
         const int rb = pos & (kRingBytes - 1);                    // wave-uniform
         if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
@@ -1158,10 +1271,8 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
-        {   // every chunk wholly below the next round's first byte is free
-            const int lim = ((pos + RBYTES) >> 10) + kRingChunks;
-            while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
-        }
+        // every chunk wholly below the next round's first byte is free
+        fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
 
         const int k0 = r * SPP;
         uint32_t mark = 0, space = 0;
@@ -1354,7 +1465,7 @@ __device__ __forceinline__ int recover_clock_index_rt(FastRing& fr, int bf) {
     return (int)wave_min_u32(cand);                             // first index of the minimal mean (ref:332-337)
 }
 
-template <int FLAGS>
+template <int FLAGS, bool HINTED>
 __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp, int byte0, int32_t K,
                                           int32_t NR, uint32_t amp_thr, RxDeferred& rd,
                                           unsigned long long* words, uint8_t* out_row, int out_stride,
@@ -1383,7 +1494,9 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp
     int pos = byte0;                                             // stream byte of the round's first sample
     for (int r = 0; r < NR; r++, pos += rbytes) {
         const int last = pos + rbytes + 3;                       // a 2-byte-aligned dword may reach 2 bytes further
-        wait_vmcnt_dyn(fr.next - 1 - (last >> 10) + ((last >> 10) < kRingChunks ? fr.warm_ops : 0));
+        if constexpr (HINTED) fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+        fr.wait_landed(last >> 10);
+        if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)bf, byte0, 4);
         const int rb = pos & (kRingBytes - 1);
         if (rb + rbytes + 4 > kRingBytes) {                      // a dword may straddle the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
@@ -1434,10 +1547,7 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp
             space = space_hi ? hall : fall - hall;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the round's reads have returned: refill
-        {
-            const int lim = ((pos + rbytes) >> 10) + kRingChunks;
-            while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
-        }
+        fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + rbytes) >> 10) + kRingChunks);
         mark = group_sum_rt(mark, lps);
         space = group_sum_rt(space, lps);
         amp = group_sum_rt(amp, lps);
@@ -1492,6 +1602,7 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)bf;
     const int byte0 = 2 * ci;
+    if (warm) fr.request_probes((uint32_t)len * 2u, byte0, spp * 2 * bf);   // tail hint (see kProbes)
     {
         const int lim = (byte0 >> 10) + kRingChunks;            // chunks entirely below the clock index are free
         while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
@@ -1499,7 +1610,8 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
-    rt_rounds<FLAGS>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    if (warm) rt_rounds<FLAGS, true>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    else rt_rounds<FLAGS, false>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     rxd_finish<32>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
@@ -1563,6 +1675,18 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
     const int byte0 = 2 * ci;                                  // ring byte of symbol 0
+    // Tail hint (see kProbes): for large launches, and only on the aligned round loops (a second copy of
+    // each, so that streams without the hint run exactly the code they ran before); not for bit_frames
+    // 4 / 8, whose five- and ten-slice rounds are so short of scalar registers that the two extra live
+    // values cost more than the saved traffic (+4 % at 6000 baud).
+    constexpr bool HINT = !OLD_SYNC && !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
+    constexpr int kAlignMask = WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15));
+    const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
+    const bool hinted = HINT && warm && aligned;
+    if (hinted) {
+        constexpr int kRoundBytes = MULTI ? 1024 * MultiGeom<MULTI ? BF : 4>::R : (WM ? WmGeom<WM ? BF : 60>::RBYTES : 5120);
+        fr.request_probes((uint32_t)len * 2u, byte0, kRoundBytes);
+    }
     // chunks entirely below the clock index are free already
     {
         const int lim = (byte0 >> 10) + kRingChunks;
@@ -1573,17 +1697,16 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
-    if constexpr (WM) {
-        if ((byte0 & (WmGeom<BF>::RW - 1)) == 0) wm_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-        else wm_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-    } else if constexpr (MULTI) {
-        if ((byte0 & (MultiGeom<BF>::RW - 1)) == 0) multi_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-        else multi_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-    } else {
-        constexpr int kAlignMask = BF == 20 ? 7 : 15;               // 2400 baud reads 8-byte pieces
-        if ((byte0 & kAlignMask) == 0) fast_rounds<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-        else fast_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-    }
+#define AFSK_ROUNDS(FN)                                                                                              \
+    do {                                                                                                             \
+        if (!aligned) FN<BF, FLAGS, false, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
+        else if (HINT && hinted) FN<BF, FLAGS, true, HINT>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
+        else FN<BF, FLAGS, true, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
+    } while (0)
+    if constexpr (WM) AFSK_ROUNDS(wm_rounds);
+    else if constexpr (MULTI) AFSK_ROUNDS(multi_rounds);
+    else AFSK_ROUNDS(fast_rounds);
+#undef AFSK_ROUNDS
     rxd_finish<PS>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released

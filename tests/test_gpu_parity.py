@@ -730,6 +730,15 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
         x = x[:L] if L <= len(x) else np.concatenate([x, np.zeros(L - len(x), np.int16)])
         if i % 7 == 0:
             x = np.clip(x.astype(np.int32) + rng.integers(-6000, 6000, len(x)), -32768, 32767).astype(np.int16)
+        # streams that defeat the tail hint of large launches (sparse amplitude probes decide how far
+        # to prefetch): a signal weaker than the squelch threshold (every probe "quiet", yet the
+        # training phase decodes it), a late start behind silence, two bursts with a silent gap
+        if i % 11 == 3:
+            x = (x.astype(np.int32) * 3 // 25).astype(np.int16)
+        elif i % 11 == 5:
+            x = np.concatenate([np.zeros(int(rng.integers(3000, 9000)), np.int16), x])
+        elif i % 11 == 8:
+            x = np.concatenate([x[: len(x) // 2], np.zeros(int(rng.integers(1500, 5000)), np.int16), x])
         pieces.append(x); bfs.append(48000 // baud)
     ln = np.array([len(p) for p in pieces], np.int32)
     off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
@@ -739,7 +748,7 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
     got = device_demod(torch, flat, off, ln, bf, stride=stride)
     want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=16)
     assert_same(got, want, "large launch")
-    assert (got.nbytes > 0).sum() > n // 2
+    assert (got.nbytes > 0).sum() > n // 3
     # the same streams in a launch below the threshold give the same answers (warming is timing only)
     sub = slice(0, 4096)
     got2 = device_demod(torch, flat[: int(off[4096])], off[sub], ln[sub], bf[sub], stride=stride)
