@@ -56,7 +56,7 @@ constexpr int kHintStashOffset = kProbeOffset + 256;            // 16 bytes: pro
 // every line is then requested twice and the request path, not HBM, becomes the limit.
 constexpr int kWarmOps = 2;
 constexpr int kWarmMinStreams = 8192;
-// Tail hint (r2, armed together with the warming, i.e. for launches of kWarmMinStreams or more).
+// Tail hint (r2, for launches of kHintMinStreams or more).
 // A stream ends in silence (4800 zero samples behind every Transmitter frame, ref:468) that the
 // reference never reads -- it stops at the first quiet symbol -- but a prefetching reader requests it
 // long before it can know: ~10 KiB are in flight when the squelch fires, i.e. the whole 9.6 KB tail.
@@ -68,6 +68,7 @@ constexpr int kWarmMinStreams = 8192;
 // on the spot (and drops the hint), so results cannot change -- e.g. a weak signal below amp_end
 // with no loud probe at all still decodes, one demand fetch later.
 constexpr int kProbes = 32;
+constexpr int kHintMinStreams = 6144;     // -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
 
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
@@ -1568,7 +1569,7 @@ template <int FLAGS>
 __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, int bf, int32_t amp_end,
                                                 uint8_t* lds, int lane, RxState& st, uint8_t* out_row,
                                                 int out_stride, int& ci_out, int32_t& n_sym_out,
-                                                int32_t* margins, int32_t mstride, bool warm) {
+                                                int32_t* margins, int32_t mstride, bool warm, bool hint) {
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
@@ -1602,7 +1603,7 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)bf;
     const int byte0 = 2 * ci;
-    if (warm) fr.request_probes((uint32_t)len * 2u, byte0, spp * 2 * bf);   // tail hint (see kProbes)
+    if (hint) fr.request_probes((uint32_t)len * 2u, byte0, spp * 2 * bf);   // tail hint (see kProbes)
     {
         const int lim = (byte0 >> 10) + kRingChunks;            // chunks entirely below the clock index are free
         while (fr.next < lim) { fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next); fr.next++; }
@@ -1610,7 +1611,7 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
-    if (warm) rt_rounds<FLAGS, true>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    if (hint) rt_rounds<FLAGS, true>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     else rt_rounds<FLAGS, false>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     rxd_finish<32>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
@@ -1624,7 +1625,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
                                                   int32_t& n_sym_out,
                                                   unsigned long long* stamps = nullptr,
                                                   int32_t* margins = nullptr, int32_t mstride = 0,
-                                                  bool warm = false) {
+                                                  bool warm = false, bool hint = false) {
     constexpr bool MULTI = MultiGeom<BF>::valid;
     constexpr bool WM = WmGeom<BF>::valid;
     constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : 2560 / BF);   // symbols per round
@@ -1682,7 +1683,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     constexpr bool HINT = !OLD_SYNC && !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
     constexpr int kAlignMask = WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15));
     const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
-    const bool hinted = HINT && warm && aligned;
+    const bool hinted = HINT && hint && aligned;
     if (hinted) {
         constexpr int kRoundBytes = MULTI ? 1024 * MultiGeom<MULTI ? BF : 4>::R : (WM ? WmGeom<WM ? BF : 60>::RBYTES : 5120);
         fr.request_probes((uint32_t)len * 2u, byte0, kRoundBytes);

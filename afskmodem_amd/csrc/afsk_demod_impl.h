@@ -574,20 +574,21 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     if constexpr (FAST) {   // single-pass ring kernel for the common bauds (afsk_demod_fast.h)
         unsigned long long* stamps = (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr;
         const bool warm = a.n_streams >= kWarmMinStreams;          // wave-uniform (afsk_demod_fast.h)
+        const bool hint = a.n_streams >= kHintMinStreams;
         done = true;
         switch (bf) {
-            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
-            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
-#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
+            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
             AFSK_FAST_CASE(4) AFSK_FAST_CASE(8) AFSK_FAST_CASE(12) AFSK_FAST_CASE(16)
             AFSK_FAST_CASE(24) AFSK_FAST_CASE(32) AFSK_FAST_CASE(48) AFSK_FAST_CASE(64)
             AFSK_FAST_CASE(60) AFSK_FAST_CASE(96) AFSK_FAST_CASE(100) AFSK_FAST_CASE(120)
 #undef AFSK_FAST_CASE
-            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
-            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm); break;
+            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
             default:            // every other valid bit_frames: the run-time geometry on the same ring
                 demod_stream_rt<FLAGS>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
-                                       margins, a.margin_stride, warm);
+                                       margins, a.margin_stride, warm, hint);
                 break;
         }
     }
