@@ -42,8 +42,8 @@ constexpr int kMirrorBytes = 256;                              // copy of ring b
 constexpr int kBitBufOffset = kRingBytes + kMirrorBytes;       // phase C's 64-word bit buffer behind the mirror
 constexpr int kBitBufBytes = 512;
 constexpr int kWarmDummyOffset = kBitBufOffset + kBitBufBytes;  // 256 bytes the warming requests may scribble on
-constexpr int kProbeOffset = kWarmDummyOffset + 256;            // 64 dwords: the tail-hint probes land here
-constexpr int kHintStashOffset = kProbeOffset + 256;            // 16 bytes: probe spacing, parked here instead of in scalar registers
+constexpr int kProbeOffset = kWarmDummyOffset + 256;            // 64 x 16 bytes: the tail-hint probes land here
+constexpr int kHintStashOffset = kProbeOffset + 1024;           // 16 bytes: probe spacing, parked here instead of in scalar registers
 
 // L2 warming behind the ring start (r2).  While a wave computes phase A its 16 ring chunks have
 // landed and it has nothing in flight -- LDS caps the ring at 16 KiB.  Right behind the 16 chunk
@@ -60,10 +60,11 @@ constexpr int kWarmMinStreams = 8192;
 // A stream ends in silence (4800 zero samples behind every Transmitter frame, ref:468) that the
 // reference never reads -- it stops at the first quiet symbol -- but a prefetching reader requests it
 // long before it can know: ~10 KiB are in flight when the squelch fires, i.e. the whole 9.6 KB tail.
-// So, once phase A is done, the wave requests kProbes single dwords, each the last dword of a round
+// So, once phase A is done, the wave requests kProbes 16-byte probes, each the last 8 samples of a round
 // (of every m-th round, so that kProbes of them cover the stream; one LDS-DMA instruction, 2 KiB of
 // HBM traffic), and when they have landed it looks for the LAST probe that is loud by the squelch's
-// own measure (|x0| + |x1| >= 2 * amp_end): the signal then ends inside the round group closed by the
+// own measure (sum of the 8 |x| >= 8 * amp_end; 8 samples, so that noise in the tail -- config #4 --
+// rarely looks loud): the signal then ends inside the round group closed by the
 // next probe, and chunks behind that group are not requested AHEAD OF NEED any more.  This is a prefetch policy only: a round that needs a chunk which was held back requests it
 // on the spot (and drops the hint), so results cannot change -- e.g. a weak signal below amp_end
 // with no loud probe at all still decodes, one demand fetch later.
@@ -108,7 +109,7 @@ struct FastRing {
 
     // Requested after phase A and before chunk 16, so the probes do not compete with the wave's first
     // 16 KiB and count like the warming requests ("between chunk 15 and chunk 16") in the waits.
-    // Probe j is the last dword below stream byte base + (j + 1) * step, step = m rounds with m chosen
+    // Probe j is the last 16 bytes (8 samples) below stream byte base + (j + 1) * step, step = m rounds with m chosen
     // so that kProbes of them cover the stream: a probe sits at the END OF A ROUND, and if it is quiet
     // and the one before it loud, the signal ends inside the rounds between them and the last chunk the
     // decoder can need is the one holding that very dword.
@@ -118,7 +119,7 @@ struct FastRing {
         const int step = (int)(((rounds + kProbes - 1) / kProbes) * (uint32_t)round_bytes);
         if (lane == 0) *reinterpret_cast<int*>(ring + kHintStashOffset) = step;
         const uint32_t po = (uint32_t)base + (uint32_t)((lane & (kProbes - 1)) + 1) * (uint32_t)step;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + kProbeOffset), 4, (int)(po - 4u), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + kProbeOffset), 16, (int)(po - 16u), 0, 0, 0);
         warm_ops += 1;
         hint_state = 1;
     }
@@ -157,9 +158,11 @@ struct FastRing {
         hint_state |= 2;
         wave_lds_sync();
         const int step = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset));
-        const uint32_t pv = *reinterpret_cast<const uint32_t*>(ring + kProbeOffset + 4 * lane);
-        const uint32_t a2 = __builtin_amdgcn_sad_u16(pv ^ kBias, kBias, 0u);               // |x0| + |x1|
-        const uint32_t mask = (uint32_t)__ballot(a2 >= 2u * amp1) & (uint32_t)((1ull << kProbes) - 1ull);
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(ring + kProbeOffset + 16 * lane);
+        uint32_t a8 = 0;                                                                   // |x0| + ... + |x7|
+#pragma unroll
+        for (int j = 0; j < 4; j++) a8 = __builtin_amdgcn_sad_u16(pv[j] ^ kBias, kBias, a8);
+        const uint32_t mask = (uint32_t)__ballot(a8 >= 8u * amp1) & (uint32_t)((1ull << kProbes) - 1ull);
         if (amp1 == 0 || (mask >> (kProbes - 1))) return;                                  // loud to the very end
         const int q = mask ? 32 - __builtin_clz(mask) : 0;                                 // first probe of the quiet tail
         hint_lim = ((base + (q + 1) * step - 1 + extra) >> 10) + 1;
@@ -221,7 +224,7 @@ constexpr int kWinExtraBytes = 2560;                           // own-LDS window
 static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
               "window LDS too small");
 constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave with the prefix window (FLAGS & 8)
-constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 17.27 KiB per wave: what the product build needs
+constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18 KiB per wave: what the product build needs
 static_assert(kHintStashOffset + 16 <= kFastWaveLds, "bit buffer / dummy / probe areas outside the diagnostic build's LDS");
 
 template <int BF, bool DEBUG = false>
