@@ -1568,11 +1568,12 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, int lps, int spp
     }
 }
 
-template <int FLAGS>
+template <int FLAGS, bool BIG = true>
 __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, int bf, int32_t amp_end,
                                                 uint8_t* lds, int lane, RxState& st, uint8_t* out_row,
                                                 int out_stride, int& ci_out, int32_t& n_sym_out,
-                                                int32_t* margins, int32_t mstride, bool warm, bool hint) {
+                                                int32_t* margins, int32_t mstride, bool warm_arg, bool hint_arg) {
+    const bool warm = BIG && warm_arg, hint = BIG && hint_arg;
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
@@ -1614,21 +1615,24 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
-    if (hint) rt_rounds<FLAGS, true>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    if (BIG && hint) rt_rounds<FLAGS, BIG>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     else rt_rounds<FLAGS, false>(fr, bf, lps, spp, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
     rxd_finish<32>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
-template <int BF, int FLAGS>
+template <int BF, int FLAGS, bool BIG = true>
 __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
                                                   uint8_t* lds, int lane, RxState& st,
                                                   uint8_t* out_row, int out_stride, int& ci_out,
                                                   int32_t& n_sym_out,
                                                   unsigned long long* stamps = nullptr,
                                                   int32_t* margins = nullptr, int32_t mstride = 0,
-                                                  bool warm = false, bool hint = false) {
+                                                  bool warm_arg = false, bool hint_arg = false) {
+    // BIG = false: the copy of this code that small launches run -- no warming, no hint, not even
+    // their tests (the extra live scalars cost config #2 1.5 % when both lived in one copy)
+    const bool warm = BIG && warm_arg, hint = BIG && hint_arg;
     constexpr bool MULTI = MultiGeom<BF>::valid;
     constexpr bool WM = WmGeom<BF>::valid;
     constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : 2560 / BF);   // symbols per round
@@ -1704,7 +1708,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
 #define AFSK_ROUNDS(FN)                                                                                              \
     do {                                                                                                             \
         if (!aligned) FN<BF, FLAGS, false, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
-        else if (HINT && hinted) FN<BF, FLAGS, true, HINT>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
+        else if (HINT && BIG && hinted) FN<BF, FLAGS, true, HINT && BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
         else FN<BF, FLAGS, true, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
     } while (0)
     if constexpr (WM) AFSK_ROUNDS(wm_rounds);

@@ -545,7 +545,7 @@ struct KernelCfg {
 };
 
 // One stream, start to finish, by one wave.
-template <int FLAGS, bool FAST>
+template <int FLAGS, bool FAST, bool BIG = true>
 __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_t off, int32_t len,
                                                int bf, uint8_t* lds, int lane) {
     const int16_t* xs = a.samples + off;
@@ -577,17 +577,17 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
         const bool hint = a.n_streams >= kHintMinStreams;
         done = true;
         switch (bf) {
-            case 40:  demod_stream_fast<40, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
-            case 20:  demod_stream_fast<20, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
-#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 40:  demod_stream_fast<40, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 20:  demod_stream_fast<20, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+#define AFSK_FAST_CASE(B) case B: demod_stream_fast<B, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
             AFSK_FAST_CASE(4) AFSK_FAST_CASE(8) AFSK_FAST_CASE(12) AFSK_FAST_CASE(16)
             AFSK_FAST_CASE(24) AFSK_FAST_CASE(32) AFSK_FAST_CASE(48) AFSK_FAST_CASE(64)
             AFSK_FAST_CASE(60) AFSK_FAST_CASE(96) AFSK_FAST_CASE(100) AFSK_FAST_CASE(120)
 #undef AFSK_FAST_CASE
-            case 80:  demod_stream_fast<80, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
-            case 160: demod_stream_fast<160, FLAGS>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 80:  demod_stream_fast<80, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
+            case 160: demod_stream_fast<160, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
             default:            // every other valid bit_frames: the run-time geometry on the same ring
-                demod_stream_rt<FLAGS>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
+                demod_stream_rt<FLAGS, BIG>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
                                        margins, a.margin_stride, warm, hint);
                 break;
         }
@@ -633,8 +633,14 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
         if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();
     }
-    process_stream<FLAGS, FAST>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
-                                lds_all + wave * kLdsPerWave, lane);
+    // two copies of the per-stream code: launches below kHintMinStreams run one that is compiled
+    // without the large-launch measures (L2 warming, tail hint)
+    if (FAST && a.n_streams >= kHintMinStreams)
+        process_stream<FLAGS, FAST, true>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
+                                          lds_all + wave * kLdsPerWave, lane);
+    else
+        process_stream<FLAGS, FAST, false>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
+                                           lds_all + wave * kLdsPerWave, lane);
     if constexpr (FLAGS & 64) {
         if (lane == 0) a.debug_stamps[4 * s + 3] = __builtin_amdgcn_s_memrealtime();
     }
