@@ -60,7 +60,7 @@ constexpr int kWarmMinStreams = 8192;
 // A stream ends in silence (4800 zero samples behind every Transmitter frame, ref:468) that the
 // reference never reads -- it stops at the first quiet symbol -- but a prefetching reader requests it
 // long before it can know: ~10 KiB are in flight when the squelch fires, i.e. the whole 9.6 KB tail.
-// So, once phase A is done, the wave requests kProbes 16-byte probes, each the last 8 samples of a round
+// So, once phase A is done, the wave requests kProbes (one per lane) 16-byte probes, each the last 8 samples of a round
 // (of every m-th round, so that kProbes of them cover the stream; one LDS-DMA instruction, 2 KiB of
 // HBM traffic), and when they have landed it looks for the LAST probe that is loud by the squelch's
 // own measure (sum of the 8 |x| >= 8 * amp_end; 8 samples, so that noise in the tail -- config #4 --
@@ -68,7 +68,7 @@ constexpr int kWarmMinStreams = 8192;
 // next probe, and chunks behind that group are not requested AHEAD OF NEED any more.  This is a prefetch policy only: a round that needs a chunk which was held back requests it
 // on the spot (and drops the hint), so results cannot change -- e.g. a weak signal below amp_end
 // with no loud probe at all still decodes, one demand fetch later.
-constexpr int kProbes = 32;
+constexpr int kProbes = 64;               // one per lane; probes beyond the stream end cost nothing (range-checked)
 constexpr int kHintMinStreams = 6144;     // -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
 
 struct FastRing {
@@ -162,9 +162,9 @@ struct FastRing {
         uint32_t a8 = 0;                                                                   // |x0| + ... + |x7|
 #pragma unroll
         for (int j = 0; j < 4; j++) a8 = __builtin_amdgcn_sad_u16(pv[j] ^ kBias, kBias, a8);
-        const uint32_t mask = (uint32_t)__ballot(a8 >= 8u * amp1) & (uint32_t)((1ull << kProbes) - 1ull);
+        const uint64_t mask = __ballot(a8 >= 8u * amp1);
         if (amp1 == 0 || (mask >> (kProbes - 1))) return;                                  // loud to the very end
-        const int q = mask ? 32 - __builtin_clz(mask) : 0;                                 // first probe of the quiet tail
+        const int q = mask ? 64 - __builtin_clzll(mask) : 0;                               // first probe of the quiet tail
         hint_lim = ((base + (q + 1) * step - 1 + extra) >> 10) + 1;
     }
 };
