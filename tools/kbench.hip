@@ -131,8 +131,9 @@ int main(int argc, char** argv) {
         {"v2 fast default-policy", launch_flags<4, true>, true},
         {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
         {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},
-        {"wpb3 lds17K (9/CU)", launch_geom<3, 17408>, true},
-        {"wpb1 lds17K (9/CU)", launch_geom<1, 17408>, true},
+        // (9 waves per CU no longer fit: a wave needs 18 KiB of LDS since the tail-hint probes)
+        {"wpb3 lds18.5K (6/CU)", launch_geom<3, 18944>, true},
+        {"wpb1 lds18.5K (8/CU)", launch_geom<1, 18944>, true},
 #endif
     };
 #ifndef KBENCH_LITE
