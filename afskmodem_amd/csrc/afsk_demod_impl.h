@@ -621,7 +621,10 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
 // no faster at 4096, so it is not used).
 // WPB = waves (= streams) per block; LDS_PER_WAVE >= 16 KiB sets how many blocks fit a CU's
 // 160 KiB LDS, i.e. the number of resident waves per CU.
-template <int FLAGS, bool FAST = true, int WPB = kWavesPerBlock, int LDS_PER_WAVE = 0>
+// BIG = the kernel for launches of kHintMinStreams or more (compiled WITH the large-launch measures:
+// L2 warming, tail hint); the other instantiation does not even contain their tests -- the extra live
+// scalars cost config #2 1.5 % when both lived in one piece of code.  launch_demod picks the kernel.
+template <int FLAGS, bool FAST = true, int WPB = kWavesPerBlock, int LDS_PER_WAVE = 0, bool BIG = false>
 __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     constexpr int kLdsPerWave = LDS_PER_WAVE > 0 ? LDS_PER_WAVE : KernelCfg<FLAGS, FAST>::kLdsPerWave;
     static_assert(kLdsPerWave >= KernelCfg<FLAGS, FAST>::kLdsPerWave, "LDS per wave too small");
@@ -633,14 +636,8 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
         if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();
     }
-    // two copies of the per-stream code: launches below kHintMinStreams run one that is compiled
-    // without the large-launch measures (L2 warming, tail hint)
-    if (FAST && a.n_streams >= kHintMinStreams)
-        process_stream<FLAGS, FAST, true>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
-                                          lds_all + wave * kLdsPerWave, lane);
-    else
-        process_stream<FLAGS, FAST, false>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
-                                           lds_all + wave * kLdsPerWave, lane);
+    process_stream<FLAGS, FAST, FAST && BIG>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
+                                             lds_all + wave * kLdsPerWave, lane);
     if constexpr (FLAGS & 64) {
         if (lane == 0) a.debug_stamps[4 * s + 3] = __builtin_amdgcn_s_memrealtime();
     }
