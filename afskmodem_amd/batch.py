@@ -220,21 +220,38 @@ def _stream_ptr(stream):
     return C.c_void_p(s.cuda_stream)
 
 
+def _uniform_bit_frames(bit_frames):
+    """The one value of a host-side bit_frames argument (int, or a sequence / array whose entries
+    are all equal), else None.  Device tensors are never inspected (that would synchronise)."""
+    if isinstance(bit_frames, (int, np.integer)):
+        return int(bit_frames)
+    if isinstance(bit_frames, (list, tuple, np.ndarray)):
+        arr = np.asarray(bit_frames)
+        if arr.ndim == 0:
+            return int(arr)
+        if arr.size and np.all(arr == arr.flat[0]):
+            return int(arr.flat[0])
+    return None
+
+
 def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshold: int = 14000,
                 out: DemodResult | None = None, out_stride: int | None = None, stream=None,
                 validate: bool = True, diagnostics: bool = False,
-                margin_stride: int | None = None) -> DemodResult:
+                margin_stride: int | None = None, entry: str = "auto") -> DemodResult:
     """One kernel launch over n independent streams resident in HBM.
 
     samples        int16 CUDA tensor holding every stream
     stream_offset  int64 CUDA tensor [n], first sample of each stream
     stream_len     int32 CUDA tensor [n]
-    bit_frames     int, sequence or tensor [n]: 48000 / baud per stream
+    bit_frames     48000 / baud: an int (one Receiver's batch: ref:275-284), or a sequence /
+                   tensor [n] with one value per stream
     out            preallocated DemodResult to reuse (no allocation in the call)
-    diagnostics    also return the soft outputs of afsk_demod_batch_ex: ``corrected`` [n] and
-                   ``margins`` [n, margin_stride] (margin_stride symbols per row; pass e.g.
-                   max_stream_len // min(bit_frames)); rows are defined up to
-                   ``DemodResult.symbols_demodulated``
+    diagnostics    also return the soft outputs: ``corrected`` [n] and ``margins`` [n, margin_stride]
+                   (margin_stride symbols per row; pass e.g. max_stream_len // min(bit_frames));
+                   rows are defined up to ``DemodResult.symbols_demodulated``
+    entry          "auto": ``afsk_demod_batch_uniform`` (a kernel compiled for exactly that
+                   geometry) when the host can see that bit_frames is one value, else the
+                   per-stream ``afsk_demod_batch`` / ``_ex``; "uniform" / "mixed" force one
     Asynchronous on ``stream`` (default: torch's current stream).
     """
     torch = _torch()
@@ -243,20 +260,26 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         raise TypeError("samples must be an int16 CUDA tensor (HBM resident)")
     if not samples.is_contiguous():
         raise ValueError("samples must be contiguous")
+    if entry not in ("auto", "uniform", "mixed"):
+        raise ValueError("entry must be 'auto', 'uniform' or 'mixed'")
     n = int(stream_offset.numel())
     dev = samples.device
     if validate and not isinstance(bit_frames, torch.Tensor):
         validate_bit_frames(bit_frames)
-    bf = _as_device_i32(bit_frames, n, dev)
     if stream_offset.dtype != torch.int64 or stream_len.dtype != torch.int32:
         raise TypeError("stream_offset must be int64 and stream_len int32")
     if not (stream_offset.is_cuda and stream_len.is_cuda):
         raise TypeError("stream_offset / stream_len must be CUDA tensors")
+    ubf = None if entry == "mixed" else _uniform_bit_frames(bit_frames)
+    if entry == "uniform" and ubf is None:
+        raise ValueError("entry='uniform' needs ONE bit_frames value (an int or an all-equal host sequence)")
     if out is None:
         if out_stride is None:
             raise ValueError("pass out= or out_stride=")
         out = alloc_result(n, int(out_stride), dev)
     stride = int(out.bytes.shape[1])
+    corrected_ptr = margins_ptr = None
+    mstride = 0
     if diagnostics:
         if out.corrected is None:
             out.corrected = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -264,19 +287,28 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
             if margin_stride is None:
                 raise ValueError("diagnostics=True needs margin_stride= (symbols per margins row)")
             out.margins = torch.zeros((n, int(margin_stride)), dtype=torch.int32, device=dev)
-        _native.check(_native.lib().afsk_demod_batch_ex(
+        corrected_ptr, margins_ptr, mstride = out.corrected.data_ptr(), out.margins.data_ptr(), int(out.margins.shape[1])
+    lib = _native.lib()
+    if ubf is not None:
+        _native.check(lib.afsk_demod_batch_uniform(
+            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), ubf,
+            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+            out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream)))
+        return out
+    bf = _as_device_i32(bit_frames, n, dev)
+    if diagnostics:
+        _native.check(lib.afsk_demod_batch_ex(
             samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
             threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
             out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-            out.status.data_ptr(), out.corrected.data_ptr(), out.margins.data_ptr(),
-            int(out.margins.shape[1]), _stream_ptr(stream)))
-        out._bf_keepalive = bf  # type: ignore[attr-defined]
-        return out
-    _native.check(_native.lib().afsk_demod_batch(
-        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
-        threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-        out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-        out.status.data_ptr(), _stream_ptr(stream)))
+            out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream)))
+    else:
+        _native.check(lib.afsk_demod_batch(
+            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
+            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+            out.status.data_ptr(), _stream_ptr(stream)))
     # keep the bit_frames tensor alive until the launch has been enqueued on the stream
     out._bf_keepalive = bf  # type: ignore[attr-defined]
     return out
@@ -406,6 +438,11 @@ def load_wav_batch(filenames, device="cuda:0"):
         samples.zero_()
     keep = np.nonzero((status == _native.WAV_OK) & (lens > 0))[0]
     if keep.size:
+        # afsk_wav_upload fills `samples` on the library's private non-blocking stream, which is not
+        # ordered against torch's streams: the caching allocator may have handed out a block that
+        # kernels still in flight on the current stream read (e.g. the previous batch's asynchronous
+        # demod_batch followed by `del`), so those must have finished before the DMA overwrites it
+        torch.cuda.current_stream(samples.device).synchronize()
         with torch.cuda.device(samples.device):
             arr = (C.c_char_p * keep.size)(*[os.fsencode(names[int(i)]) for i in keep])
             k_off, k_bytes, k_dst = (np.ascontiguousarray(a[keep]) for a in (d_off, d_bytes, offs))

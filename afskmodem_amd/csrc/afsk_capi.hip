@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -274,8 +275,28 @@ private:
     uint64_t gen_ = 0;
     bool quit_ = false;
 };
+// Never destroyed (no join of parked threads at process exit) and FORK-SAFE: after fork() the child
+// has the parent's pool object but none of its threads -- run() would wait for workers that do not
+// exist -- so a pthread_atfork child handler abandons the inherited pool (leaked on purpose: its
+// std::thread objects are joinable and its mutexes may be held by threads that are gone) and the
+// child's first call builds a fresh one.
+std::atomic<IoPool*> g_io_pool{nullptr};
+std::mutex g_io_pool_mu;
+void io_pool_after_fork_in_child() {
+    g_io_pool.store(nullptr, std::memory_order_relaxed);
+    new (&g_io_pool_mu) std::mutex();            // the parent may have held it at fork time
+}
 IoPool& io_pool() {
-    static IoPool* p = new IoPool();     // never destroyed: no join of parked threads at process exit
+    IoPool* p = g_io_pool.load(std::memory_order_acquire);
+    if (p) return *p;
+    std::lock_guard<std::mutex> lk(g_io_pool_mu);
+    p = g_io_pool.load(std::memory_order_relaxed);
+    if (!p) {
+        static const int registered = pthread_atfork(nullptr, nullptr, io_pool_after_fork_in_child);
+        (void)registered;
+        p = new IoPool();
+        g_io_pool.store(p, std::memory_order_release);
+    }
     return *p;
 }
 template <class F>
@@ -459,6 +480,53 @@ int afsk_demod_batch_ex(const int16_t* samples, const int64_t* stream_offset,
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel");
 }
 
+int afsk_demod_batch_uniform(const int16_t* samples, const int64_t* stream_offset,
+                             const int32_t* stream_len, int32_t bit_frames,
+                             int32_t amp_end_threshold, int32_t n_streams, uint8_t* out_bytes,
+                             int32_t out_stride, int32_t* out_nbytes, int32_t* out_nbits,
+                             int32_t* out_clock_idx, int32_t* out_term_frame, int32_t* out_status,
+                             int32_t* out_corrected, int32_t* out_margins, int32_t margin_stride,
+                             void* hip_stream) {
+    if (n_streams < 0 || out_stride < 0 || margin_stride < 0)
+        return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (bit_frames < 4 || (bit_frames & 3) || 2 * bit_frames >= AFSK_SYNC_WINDOW)
+        return fail(AFSK_E_INVALID_BAUD, "bit_frames must be a multiple of 4 with 2*bf < 4096");
+    if (n_streams == 0) return AFSK_OK;
+    if (!samples || !stream_offset || !stream_len || !out_nbytes || !out_nbits ||
+        !out_clock_idx || !out_term_frame || !out_status || (!out_bytes && out_stride > 0))
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    if (int rc = require_device()) return rc;
+    afsk::DemodArgs a;
+    a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
+    a.bit_frames = nullptr; a.uniform_bit_frames = bit_frames;
+    a.amp_end = amp_end_threshold; a.n_streams = n_streams;
+    a.out_bytes = out_bytes; a.out_stride = out_stride; a.out_nbytes = out_nbytes;
+    a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
+    a.out_status = out_status;
+    a.out_corrected = out_corrected;
+    a.out_margins = margin_stride > 0 ? out_margins : nullptr;
+    a.margin_stride = margin_stride;
+    hipError_t e = afsk::launch_demod_uniform(a, (hipStream_t)hip_stream);
+    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel");
+}
+
+// The host entries see the bit_frames array: one value for all streams -> the uniform kernel.
+static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples, const int64_t* stream_offset,
+                             const int32_t* stream_len, const int32_t* d_bit_frames, int32_t amp_end_threshold,
+                             int32_t n_streams, uint8_t* out_bytes, int32_t out_stride, int32_t* out_nbytes,
+                             int32_t* out_nbits, int32_t* out_clock_idx, int32_t* out_term_frame,
+                             int32_t* out_status, hipStream_t stream) {
+    bool same = true;
+    for (int32_t s = 1; s < n_streams && same; s++) same = h_bit_frames[s] == h_bit_frames[0];
+    if (same)
+        return afsk_demod_batch_uniform(samples, stream_offset, stream_len, h_bit_frames[0], amp_end_threshold,
+                                        n_streams, out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx,
+                                        out_term_frame, out_status, nullptr, nullptr, 0, stream);
+    return afsk_demod_batch(samples, stream_offset, stream_len, d_bit_frames, amp_end_threshold, n_streams,
+                            out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx, out_term_frame,
+                            out_status, stream);
+}
+
 static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
                                  const int64_t* stream_offset, const int32_t* stream_len,
                                  const int32_t* bit_frames, int32_t amp_end_threshold,
@@ -515,11 +583,11 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
              "H2D stream index");
     {
         int32_t* i32 = (int32_t*)(d_all + o_out);
-        rc = afsk_demod_batch((const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
-                              (const int32_t*)(d_all + o_meta + n * 8),
-                              (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
-                              (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
-                              i32 + 3 * n, i32 + 4 * n, stream);
+        rc = demod_device_auto(bit_frames, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+                               (const int32_t*)(d_all + o_meta + n * 8),
+                               (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
+                               (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
+                               i32 + 3 * n, i32 + 4 * n, stream);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -646,11 +714,11 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
              "H2D stream index");
     {
         int32_t* i32 = (int32_t*)(d_all + o_out);
-        rc = afsk_demod_batch((const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
-                              (const int32_t*)(d_all + o_meta + n * 8),
-                              (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
-                              (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
-                              i32 + 3 * n, i32 + 4 * n, stream);
+        rc = demod_device_auto(bit_frames, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+                               (const int32_t*)(d_all + o_meta + n * 8),
+                               (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
+                               (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
+                               i32 + 3 * n, i32 + 4 * n, stream);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -765,7 +833,28 @@ static int wav_upload_impl(const char* const* paths, const int64_t* data_offset,
                 rc = fail(AFSK_E_HOST, std::string("cannot read ") + paths[io_failed.load()]);
                 goto done;
             }
-            AFSK_HIP(hipMemcpyAsync((char*)d_samples + w0, st, w1 - w0, hipMemcpyHostToDevice, stream), "H2D samples");
+            // Only the stream pieces of the window were filled.  Send it as contiguous RUNS of pieces:
+            // an alignment gap of up to kGapFill bytes between two streams is zero-filled and travels with
+            // the run (one copy per stream would cost more than the transfer); a larger gap -- room the
+            // caller keeps for streams it fills some other way -- ends the run and is never written.
+            {
+                constexpr size_t kGapFill = 256;
+                size_t run0 = 0, run1 = 0;                              // window-relative byte range of the open run
+                bool open = false;
+                for (const Piece& p : pieces) {
+                    const size_t a0 = (size_t)(p.dst - st), a1 = a0 + p.bytes;
+                    if (open && a0 - run1 <= kGapFill) {
+                        if (a0 > run1) std::memset(st + run1, 0, a0 - run1);
+                        run1 = a1;
+                        continue;
+                    }
+                    if (open)
+                        AFSK_HIP(hipMemcpyAsync((char*)d_samples + w0 + run0, st + run0, run1 - run0, hipMemcpyHostToDevice, stream), "H2D samples");
+                    run0 = a0; run1 = a1; open = true;
+                }
+                if (open)
+                    AFSK_HIP(hipMemcpyAsync((char*)d_samples + w0 + run0, st + run0, run1 - run0, hipMemcpyHostToDevice, stream), "H2D samples");
+            }
             AFSK_HIP(hipEventRecord(stage_free[k & 1], stream), "hipEventRecord");
         }
     }

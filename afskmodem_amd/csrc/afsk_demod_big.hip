@@ -5,7 +5,7 @@
 namespace afsk {
 
 hipError_t launch_demod_big(const DemodArgs& a, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((demod_kernel_t<0, true, kWavesPerBlock, 0, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+    hipLaunchKernelGGL((demod_kernel_t<0, kWavesPerBlock, 0, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                        stream, a);
     return hipGetLastError();
 }

@@ -4,8 +4,10 @@
 //   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks, several
 //                                                              symbols per lane
 //   60 / 96 / 100 / 120  (800 / 500 / 480 / 400 baud)          wm_rounds: rounds of any size, watermark refill
-// and every other valid bit_frames (128 and above: 375 baud and below, outside the documented range
-// but decodable by the reference's code) with a geometry computed at run time (rt_rounds).
+// and every other valid bit_frames -- every multiple of 4 below 2048 that is not listed above: 28, 36,
+// 44 ... 124 (reachable as int(48000 / baud)) and 128 and above (375 baud and below, outside the
+// documented range but decodable by the reference's code) -- with a geometry computed at run time
+// (rt_rounds).
 //
 // Every sample is fetched from HBM exactly once: the wave starts a 16 KiB LDS-DMA
 // ring at sample 0 the moment it starts, BEFORE the clock index is known, so the
@@ -18,9 +20,8 @@
 //   phase A   ref:322-339 once chunks 0..7 have landed: lane-wise sliding correlation
 //             (recover_clock_index_lanes for bit_frames <= 120, _lane_steps for 160): every lane keeps the raw samples of
 //             its own run of consecutive sync offsets in registers and slides the SAD with 7
-//             v_dot2c_i32_i16 per offset.  The first design (a DPP prefix-sum producer feeding
-//             a circular LDS window, 7 lookups per offset: recover_clock_index_fast) is kept
-//             behind the diagnostic FLAGS & 8 for A/B runs; it was LDS-bandwidth bound.
+//             v_dot2c_i32_i16 per offset.  (The first design -- a DPP prefix-sum producer feeding a
+//             circular LDS window, 7 lookups per offset -- was LDS-bandwidth bound and is gone.)
 //   phase B   ref:342-351: every lane owns an 80-byte piece (40 samples: one
 //             1200-baud symbol, two 2400-baud symbols, half a 600-baud or a quarter of a
 //             300-baud symbol) at ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as five
@@ -165,7 +166,11 @@ struct FastRing {
         const uint64_t mask = __ballot(a8 >= 8u * amp1);
         if (amp1 == 0 || (mask >> (kProbes - 1))) return;                                  // loud to the very end
         const int q = mask ? 64 - __builtin_clzll(mask) : 0;                               // first probe of the quiet tail
-        hint_lim = ((base + (q + 1) * step - 1 + extra) >> 10) + 1;
+        // 64-bit: (q + 1) * step reaches span + 64 rounds, more than the 2^16-byte headroom of
+        // AFSK_MAX_STREAM_LEN leaves below 2^31
+        const uint64_t last = (uint64_t)(uint32_t)base + (uint64_t)(uint32_t)(q + 1) * (uint64_t)(uint32_t)step - 1u + (uint32_t)extra;
+        const uint64_t lim = (last >> 10) + 1u;
+        hint_lim = lim < 0x7fffffffull ? (int)lim : 0x7fffffff;
     }
 };
 
@@ -178,187 +183,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// Geometry of the prefix-window clock search (first design, FLAGS & 8 only) for one baud rate.
-// Prefix sums live in a circular window
-// of PW int32 entries that occupies ring slots 12..15 while phase A runs (those chunks are
-// requested only afterwards).  A producer step turns 256 raw samples (4 per lane) into prefix
-// sums; a consumer step evaluates OC = 64*GC sync offsets (GC per lane), so the LDS round trip
-// of its 7*GC window reads is paid once per OC offsets -- phase A is latency-bound, not
-// throughput-bound, and this is what makes it short.
-template <int BF>
-struct SyncGeom {
-    static constexpr int N = 2 * BF;
-    static constexpr int GC = BF <= 64 ? 4 : 2;                // offsets per lane per consumer step
-    static constexpr int OC = 64 * GC;
-    static constexpr int PW = BF <= 64 ? 512 : 1024;           // window entries (2 or 4 producer steps)
-    static constexpr int NOFF = kSync - N;                     // ref:327
-    static constexpr int T = (NOFF + OC - 1) / OC;             // consumer steps
-    static constexpr int PSTEPS = kSync / 256;                 // 16 producer steps
-    // producer steps that must be complete before consumer step t
-    static constexpr int done_before(int t) {
-        if (t < 0) return 0;
-        const int need = (OC * t + OC - 1 + N) / 256 + 1;
-        return need > PSTEPS ? PSTEPS : need;
-    }
-    // the newest step produced for consumer t must not overwrite the oldest one it still reads
-    static constexpr bool window_ok() {
-        for (int t = 0; t < T; t++)
-            if (done_before(t) - 1 - PW / 256 >= (OC * t) / 256) return false;
-        return true;
-    }
-    // BF <= 64: the first N entries of every even producer step are stored a second time past
-    // the end of the window, so a consumer's reads never wrap and need no address masking.
-    static constexpr int MIRROR = BF <= 64 ? ((N + 3) / 4) * 4 : 0;
-    static constexpr int WIN_BYTES = (PW + MIRROR) * 4;
-    // Where the window lives and how much of the stream is requested before phase A:
-    //   BF <= 64  2.4 KiB window in its own LDS behind the ring; all 16 chunks requested up
-    //             front (phase A takes about as long as 16 KiB take to arrive);
-    //   BF  > 64  4 KiB window inside ring slots 12..15; chunks 0..11 requested up front, the
-    //             rest right after phase A.
-    static constexpr bool WIN_IN_RING = BF > 64;
-    static constexpr int SYNC_CHUNKS = WIN_IN_RING ? 12 : kRingChunks;
-    static constexpr int WIN_OFFSET = WIN_IN_RING ? 12 * 1024 : kRingBytes;
-    static_assert(!WIN_IN_RING || WIN_BYTES <= 4096, "window must fit ring slots 12..15");
-};
-constexpr int kWinExtraBytes = 2560;                           // own-LDS window of the BF <= 64 paths
-static_assert(SyncGeom<20>::WIN_BYTES <= kWinExtraBytes && SyncGeom<40>::WIN_BYTES <= kWinExtraBytes,
-              "window LDS too small");
-constexpr int kFastWaveLds = kRingBytes + kWinExtraBytes;      // 18.5 KiB per wave with the prefix window (FLAGS & 8)
-constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18 KiB per wave: what the product build needs
-static_assert(kHintStashOffset + 16 <= kFastWaveLds, "bit buffer / dummy / probe areas outside the diagnostic build's LDS");
-
-template <int BF, bool DEBUG = false>
-__device__ __forceinline__ int recover_clock_index_fast(FastRing& fr, int32_t* pw,
-                                                        uint32_t* dbg = nullptr,
-                                                        unsigned long long* stamps = nullptr) {
-    using G = SyncGeom<BF>;
-    constexpr int N = G::N, Q = BF / 4, H = BF / 2, PW = G::PW, GC = G::GC, OC = G::OC;
-    constexpr int NOFF = G::NOFF, T = G::T;
-    static_assert(G::window_ok(), "prefix window too small for this baud");
-    constexpr uint32_t C = 65535u * (uint32_t)BF;
-    // floor(m / N) for m < 2^27 as mul_hi(m, M) >> 4 with M = ceil(2^36 / N):
-    // error term m * (M*N - 2^36) < 2^27 * N <= 2^36 for N <= 512.
-    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
-    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
-    const int lane = fr.lane;
-    using std::integral_constant;
-
-    // ---- producer: 256 raw samples (4 per lane) -> 256 exclusive prefix sums in the window
-    int32_t carry = 0;
-    u32x2 raw_next;
-    auto load_raw = [&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if constexpr (u < G::PSTEPS) {
-            if constexpr ((u & 1) == 0) wait_vmcnt<G::SYNC_CHUNKS - 1 - u / 2>();   // chunk u/2 has landed
-            if constexpr (u == 0) { if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime(); }
-            raw_next = *reinterpret_cast<const u32x2*>(fr.ring + 512 * u + 8 * lane);
-        }
-    };
-    auto produce = [&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const u32x2 w = raw_next;
-        load_raw(integral_constant<int, u + 1>{});          // prefetch the next step's samples
-        const int32_t x0 = ((int32_t)(w[0] << 16)) >> 16, x1 = ((int32_t)w[0]) >> 16;
-        const int32_t x2 = ((int32_t)(w[1] << 16)) >> 16, x3 = ((int32_t)w[1]) >> 16;
-        const int32_t e1 = x0, e2 = x0 + x1, e3 = e2 + x2, tot = e3 + x3;
-        const int32_t incl = wave_incl_scan_dpp(tot);
-        const int32_t base = carry + incl - tot;
-        constexpr int j0 = (256 * u) % PW;
-        const u32x4 pv = {(uint32_t)base, (uint32_t)(base + e1), (uint32_t)(base + e2),
-                          (uint32_t)(base + e3)};                // P[256u + 4*lane + 0..3]
-        *reinterpret_cast<u32x4*>(pw + j0 + 4 * lane) = pv;
-        if constexpr (G::MIRROR > 0 && j0 == 0) {
-            if (4 * lane < G::MIRROR) *reinterpret_cast<u32x4*>(pw + PW + 4 * lane) = pv;
-        }
-        carry += __builtin_amdgcn_readlane(incl, 63);
-    };
-
-    // ---- consumer: total(i) = sum_j |tc[j] - x[i+j]| for the GC CONSECUTIVE offsets
-    // i = OC*t + GC*lane + k of each lane, so one wide LDS read fetches P[i+e .. i+e+GC-1].
-    // Pass 1 keeps every total in registers and tracks the minimum; the first offset whose
-    // truncated mean equals the minimal one is found in pass 2 without a division per offset.
-    uint32_t totals[T * GC];
-    uint32_t min_total = 0xFFFFFFFFu;
-    int lane_t = lane;     // address seed of the window reads, re-defined after every step (below)
-    auto load_span = [&](auto cc, int32_t (&v)[GC]) {
-        constexpr int c = decltype(cc)::value;                // window entry of lane 0's first offset
-        constexpr bool wraps = c + 64 * GC > PW + G::MIRROR;  // some lane would run past the window
-        const int32_t* p = wraps ? pw + ((c + GC * lane_t) & (PW - 1)) : pw + c + GC * lane_t;
-        if constexpr (GC == 4 && c % 4 == 0) {
-            const u32x4 q4 = *reinterpret_cast<const u32x4*>(p);
-            v[0] = (int32_t)q4[0]; v[1] = (int32_t)q4[1]; v[2] = (int32_t)q4[2]; v[3] = (int32_t)q4[3];
-        } else if constexpr (c % 2 == 0) {
-#pragma unroll
-            for (int k = 0; k < GC; k += 2) {
-                const u32x2 q2 = *reinterpret_cast<const u32x2*>(p + k);
-                v[k] = (int32_t)q2[0]; v[k + 1] = (int32_t)q2[1];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < GC; k++) v[k] = p[k];
-        }
-    };
-    static_assert(PW % GC == 0 && (BF > 64 || G::MIRROR >= N), "span reads must not straddle the wrap");
-
-    load_raw(integral_constant<int, 0>{});
-    static_for<0, G::done_before(0)>([&](auto uc) { produce(uc); });
-    wave_lds_sync();                                         // other lanes read these stores
-    static_for<0, T>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int cb = (OC * t) % PW;
-        // (1) issue this step's window reads
-        int32_t r[7][GC];
-        load_span(integral_constant<int, (cb + 0) % PW>{}, r[0]);
-        load_span(integral_constant<int, (cb + Q) % PW>{}, r[1]);
-        load_span(integral_constant<int, (cb + 2 * Q) % PW>{}, r[2]);
-        load_span(integral_constant<int, (cb + 3 * Q) % PW>{}, r[3]);
-        load_span(integral_constant<int, (cb + BF) % PW>{}, r[4]);
-        load_span(integral_constant<int, (cb + BF + H) % PW>{}, r[5]);
-        load_span(integral_constant<int, (cb + N) % PW>{}, r[6]);
-        // (2) while they are in flight, produce what the NEXT consumer step needs.  LDS executes
-        //     a wave's operations in order, so the reads above still see the old window content
-        //     -- provided the compiler keeps them above the stores below: per thread they do not
-        //     alias, so only a fence pins that order.
-        constexpr int u0 = G::done_before(t), u1 = G::done_before(t + 1);
-        if constexpr (t + 1 < T && u1 > u0) wave_lds_sync();
-        if constexpr (t + 1 < T) {
-            static_for<u0, u1>([&](auto uc) { produce(uc); });
-            if constexpr (u1 > u0) wave_lds_sync();
-        }
-        // (3) arithmetic of this step
-#pragma unroll
-        for (int k = 0; k < GC; k++) {
-            const int32_t tt = r[0][k] + r[6][k] + 2 * (r[2][k] + r[4][k] - r[1][k] - r[3][k] - r[5][k]);
-            uint32_t total = C + (uint32_t)tt;
-            const int i = OC * t + GC * lane + k;
-            if constexpr (DEBUG) dbg[i] = total;
-            if constexpr (OC * t + OC - 1 >= NOFF) total = (i < NOFF) ? total : 0xFFFFFFFFu;
-            totals[t * GC + k] = total;
-            min_total = total < min_total ? total : min_total;
-        }
-        // Tie the next step's read addresses to this step's result: without it hipcc issues the
-        // window reads of many steps ahead and parks them in registers (256 VGPR + 130 AGPR,
-        // one wave per SIMD instead of two).
-        {
-            int lt = lane_t;
-            uint32_t mt = min_total;
-            asm volatile("" : "+v"(lt), "+v"(mt));
-            lane_t = lt;
-            min_total = mt;
-        }
-    });
-    // ---- pass 2: first index whose mean int(total / N) is minimal (strict <, ref:332-337)
-    const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
-    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
-    uint32_t cand = 0xFFFFFFFFu;
-    static_for<0, T * GC>([&](auto kc) {
-        constexpr int k = T * GC - 1 - decltype(kc)::value;                // last to first: first wins
-        constexpr int i0 = OC * (k / GC) + (k % GC);                       // offset of lane 0
-        cand = totals[k] < bound ? (uint32_t)(i0 + GC * lane) : cand;
-    });
-    cand = wave_min_u32(cand);
-    return (int)__builtin_amdgcn_readfirstlane(cand);
-}
+constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18,448 B of LDS per wave
 
 // ---- phase A, lane-wise form (every single-pass bit_frames up to 120) --------------------
 // Every lane owns GC = 72 CONSECUTIVE sync offsets and the GC + 2*BF raw samples they touch,
@@ -1041,9 +866,8 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
 // bit_frames 4 / 8 / 12 / 16 / 24 / 32 / 48 / 64 (12000 ... 750 baud).  A round is R chunks =
 // 64 * SPL symbols; lane l takes symbols l, l + 64, ... (SPL pieces of 2*BF bytes, read with
 // 16-byte loads when BF % 8 == 0, 8-byte loads otherwise), so every 64-symbol slice of the round is
-// one plain ballot -- the 2400-baud scheme with other sizes.  (The remaining valid bit_frames --
-// 60, 96, 100, 120 and above 160 -- have no round of whole chunks that leaves enough of the ring
-// in flight and stay on the two-pass path.)
+// one plain ballot -- the 2400-baud scheme with other sizes.  (60, 96, 100 and 120 have no round of
+// whole chunks that leaves enough of the ring in flight: wm_rounds below.)
 template <int BF>
 struct MultiGeom {
     static constexpr bool valid = BF == 4 || BF == 8 || BF == 12 || BF == 16 || BF == 24 || BF == 32 ||
@@ -1337,8 +1161,8 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
 }
 
 // ---- every other valid bit_frames (a RUNTIME value) on the single-pass ring -------------------
-// bit_frames 128 and above (375 baud and below: outside the reference's documented range, but its
-// code decodes them).  Same ring, watermark refill and mirror as wm_rounds; the symbol geometry is
+// Every valid bit_frames without a compile-time geometry: 28, 36, 44 ... 124 and everything from 128 up
+// (375 baud and below: outside the reference's documented range, but its code decodes them).  Same ring, watermark refill and mirror as wm_rounds; the symbol geometry is
 // computed at run time:
 //   * lps lanes per symbol (2, 4, 8 or 16: the largest split that keeps a lane piece an even number
 //     of samples and, where possible, at most 64 samples), spp symbols per round (a power of two, a
@@ -1641,13 +1465,11 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     fr.ring = lds;
     fr.lane = lane;
     // the lane-wise clock recovery needs no LDS of its own: the whole ring is requested at once
-    // (the prefix-window form of kbench's FLAGS & 8 keeps its window in ring slots 12..15 for BF > 64)
-    constexpr bool OLD_SYNC = (FLAGS & 8) && !MULTI && !WM;
-    constexpr int PRE = OLD_SYNC ? SyncGeom<(MULTI || WM) ? 40 : BF>::SYNC_CHUNKS : kRingChunks;
+    constexpr int PRE = kRingChunks;
 #pragma unroll
     for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
     fr.next = PRE;
-    if (warm && !OLD_SYNC) {
+    if (warm) {
 #pragma unroll
         for (int p = 0; p < kWarmOps; p++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(fr.rsrc, AFSK_LDS(lds + kWarmDummyOffset), 4, lane * 64,
@@ -1662,13 +1484,10 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
         // not: 72 + 320 samples), sub-windows in steps otherwise
         constexpr bool LANES_FORM = BF <= 120;
-        if constexpr (LANES_FORM && !OLD_SYNC)
+        if constexpr (LANES_FORM)
             ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
-        else if constexpr (!OLD_SYNC)
-            ci = recover_clock_index_lane_steps<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else
-            ci = recover_clock_index_fast<BF>(fr, reinterpret_cast<int32_t*>(lds + SyncGeom<BF>::WIN_OFFSET), nullptr,
-                                              (FLAGS & 64) ? stamps : nullptr);
+            ci = recover_clock_index_lane_steps<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
     }
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1687,7 +1506,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     // each, so that streams without the hint run exactly the code they ran before); not for bit_frames
     // 4 / 8, whose five- and ten-slice rounds are so short of scalar registers that the two extra live
     // values cost more than the saved traffic (+4 % at 6000 baud).
-    constexpr bool HINT = !OLD_SYNC && !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
+    constexpr bool HINT = !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
     constexpr int kAlignMask = WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15));
     const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
     const bool hinted = HINT && hint && aligned;

@@ -9,7 +9,7 @@ struct DemodArgs {
     const int16_t* samples;
     const int64_t* stream_offset;
     const int32_t* stream_len;
-    const int32_t* bit_frames;
+    const int32_t* bit_frames;                    // [n] per-stream values (mixed-baud kernel); unused by the uniform kernels
     int32_t amp_end;
     int32_t n_streams;
     uint8_t* out_bytes;
@@ -24,6 +24,7 @@ struct DemodArgs {
     int32_t* out_corrected = nullptr;             // [n] codewords with a non-zero Hamming syndrome
     int32_t* out_margins = nullptr;               // [n, margin_stride] space_diff - mark_diff per symbol
     int32_t margin_stride = 0;
+    int32_t uniform_bit_frames = 0;               // the one bit_frames of a uniform launch (afsk_demod_batch_uniform)
 };
 
 struct ModulateArgs {
@@ -69,6 +70,8 @@ struct GateArgs {
 
 hipError_t launch_gate(const GateArgs& a, hipStream_t stream);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
+// one bit_frames (a.uniform_bit_frames, host-validated) for every stream of the launch
+hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream);
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);
 hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream);
 

@@ -3,20 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (afsk_demod_batch: sync search + symbol correlator +
-squelch + Hamming decode + byte pack) over one batch of synthetic streams already resident in
-HBM.  Prints ONE JSON line (contract in the task statement).
+One "step" = one pass of the hot path (sync search + symbol correlator + squelch + Hamming decode +
+byte pack: afsk_demod_batch_uniform for a one-rate batch, afsk_demod_batch for a mixed one) over one
+batch of synthetic streams already resident in HBM.  Prints ONE JSON line (contract in the task
+statement).
 
-Workloads (BASELINE.json configs[1..4]):
-  config2  4096 x 1 s @1200 baud, clean            -- the headline workload at N = 1
-  config3  65536 x 1 s mixed {300,1200,2400} baud  -- sub-record at N = 1
-  config4  65536 x 1 s @1200 baud + noise          -- sub-record at N = 1: timed at 10 dB, plus
-                                                      the BER curve 30 -> 5 dB vs the CPU oracle
-  config5  65536 x 1 s @1200 baud per GPU          -- the headline workload at N > 1 (the shard
-                                                      north_star names: 524288 streams on 8 GPUs);
-                                                      sub-record at N = 1 (1-GPU point of its curve)
-At N > 1 the config2 shard is carried as a sub-record, so both weak-scaling curves (4096 and
-65536 streams per GPU) can be read off the N = 1, 2, 4, 8 lines (`per_workload_value`).
+The HEADLINE workload is the same at every N: the config5 shard -- BASELINE.json configs[4],
+65536 streams x 1 s @1200 baud PER GPU (524288 on 8), the largest single-GPU configuration and the
+one north_star names -- so the N = 1, 2, 4, 8 lines form one weak-scaling curve and value(1) of a
+scaling run equals the N = 1 bench line.  At N = 1 the other configs ride along as `sub_records`:
+  config2  4096 x 1 s @1200 baud, clean (configs[1])
+  config3  65536 x 1 s mixed {300,1200,2400} baud (configs[2]), with a CPU baseline per baud share
+  config4  65536 x 1 s @1200 baud + noise (configs[3]): timed at 10 dB, plus the BER curve 30 -> 0 dB
+           vs the CPU oracle
+and so do the three built "next" rows of SURVEY 8(f), each with its own roofline and oracle check:
+  f1_modulate    on-device modulator (write-bound, config5 shape)
+  f2_gate        live-gate replay (read-bound) over 4096 and 65536 captures
+  f3_wav_ingest  4096 .wav files -> device layout (PCIe-bound: against a pinned hipMemcpy of the bytes)
+At N > 1 the config2 shard is carried as a sub-record (worst case for the per-collective cost).
+
+Timing: a timed region is EXACTLY K steps between two fences (barrier + synchronize on both sides);
+when one region is shorter than --min-region-ms (50 ms) the K-step region is repeated and `value` /
+`ms_per_step` are those of the MEDIAN region (`timed_regions`, `timed_region_ms`).  HIP events inside the
+regions give the per-step median (`event_ms_per_step_median`) and the average launch duration the
+roofline uses (`roofline.kernel_ms`).
 
 Launching: `python bench.py --gpus N` with N > 1 from a bare interpreter starts N rank processes
 itself (torch.distributed.run on a free port) BEFORE anything touches the GPU and relays rank 0's
@@ -49,14 +59,16 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     # name: (streams per GPU, bauds cycled over streams, snr_db or None, description)
+    "config5": (65536, (1200,), None, "configs[4]: 65536 streams x 1 s @1200 baud, clean, per GPU (524288 on 8)"),
     "config2": (4096, (1200,), None, "configs[1]: 4096 streams x 1 s @1200 baud, clean, per GPU"),
     "config3": (65536, (300, 1200, 2400), None, "configs[2]: 65536 streams x 1 s mixed baud {300,1200,2400}, clean, per GPU"),
     "config4": (65536, (1200,), 10.0, "configs[3]: 65536 streams x 1 s @1200 baud, additive noise SNR 10 dB, per GPU"),
-    "config5": (65536, (1200,), None, "configs[4]: 65536 streams x 1 s @1200 baud, clean, per GPU (524288 on 8)"),
     # not a BASELINE config: --workload custom --bauds 480,12000 [--streams N] times any baud mix
     # (profiles of the rates furthest from the roofline)
     "custom": (4096, (1200,), None, "custom: streams x 1 s, clean, bauds from --bauds, per GPU"),
 }
+HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
+NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest")   # SURVEY 8(f) rows carried as sub-records at N = 1
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
 STREAM_LEN = 48000
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -75,6 +87,35 @@ def kernel_source_hash() -> str:
             h.update(fn.encode())
             h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
+
+
+def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
+    """What one run measures -- pure, no GPU (tests/test_bench_launch.py checks it on CPU).
+    The headline is the SAME workload at every N; the defaults only differ in what rides along."""
+    main = workload or HEADLINE
+    if sub is not None:
+        names = [x for x in sub.split(",") if x]
+    elif workload or streams:
+        names = []
+    else:
+        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) if world == 1 else ["config2"]
+    for x in [main] + names:
+        if x not in WORKLOADS and x not in NEXT_ROWS:
+            raise SystemExit(f"unknown workload {x}")
+    if main in NEXT_ROWS:
+        raise SystemExit("the next rows (f1/f2/f3) are sub-records, not headline workloads")
+    return {"main": main, "subs": [x for x in names if x in WORKLOADS and x != main],
+            "next": [x for x in names if x in NEXT_ROWS]}
+
+
+def config_block(name: str, n_local: int, world: int, backend: str = "nccl", share_gpu0: bool = False) -> dict:
+    """The `config` object of the result line (no GPU needed to build it)."""
+    _, bauds, snr, desc = WORKLOADS[name]
+    par = f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")
+    if backend != "nccl":
+        par += " [DIAGNOSTIC: gloo backend" + (", all ranks on one GPU" if share_gpu0 else "") + "]"
+    return {"workload": desc, "streams_per_gpu": n_local, "streams_total": n_local * world,
+            "stream_len": STREAM_LEN, "bauds": list(bauds), "snr_db": snr, "parallelism": par}
 
 
 def free_port() -> int:
@@ -207,6 +248,8 @@ class Shard:
             copies = min(copies, 8)
         for _ in range(copies - 1):
             self.inputs.append(x.clone())
+        # one baud rate in the whole shard -> the Receiver-shaped uniform entry (bit_frames by value)
+        self.uniform_bf = int(self.bf_h[0]) if (len(set(bauds)) == 1 and ctx.args.entry != "mixed") else None
         self.stride = batch.out_stride_for(STREAM_LEN, int(self.bf_h.min()))
         _, self.flat_sz = batch.flat_layout(n_local, self.stride)
         torch.cuda.synchronize()
@@ -244,10 +287,18 @@ def weighted_sum(torch, flat):
     return (flat.to(torch.int64) * w).sum()
 
 
-def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gather_every: int = 0):
-    """Pre-roll, W warm-up steps, then exactly K timed steps between two fences.  Every step
-    writes its own output slot; with a process group the slots of G consecutive steps are
-    all-gathered by ONE collective on a side stream while the next group runs."""
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else None
+
+
+def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gather_every: int = 0,
+            min_region_ms: float = 50.0, max_regions: int = 64):
+    """Pre-roll, W warm-up steps, then timed regions of EXACTLY K steps between two fences each: one
+    region, or -- when a region is shorter than min_region_ms -- as many as add up to it; the reported
+    region is the median one.  Every step writes its own output slot; with a process group the slots
+    of G consecutive steps are all-gathered by ONE collective on a side stream while the next group
+    runs."""
     from afskmodem_amd import _native, batch
     torch, dist = ctx.torch, ctx.dist
     cur, comm = ctx.cur, ctx.comm
@@ -256,10 +307,10 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
 
     # Each collective costs the compute stream ~40 us (cross-stream events around it),
     # so a group should cover a few ms of kernels: 64 steps of config #2, 3-4 of the 6.29 GB ones.
+    est_step_s = 2.0 * n_local * STREAM_LEN / 6.0e12
     if gather_every > 0:
         G = gather_every
     else:
-        est_step_s = 2.0 * n_local * STREAM_LEN / 6.0e12
         G = max(1, min(64, int(4e-3 / est_step_s)))
     if comm is None:
         G = 1
@@ -276,13 +327,20 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     gathered_once = [False] * ngroups
 
     sptr = C.c_void_p(cur.cuda_stream)
-    fn = ctx.lib.afsk_demod_batch
     nin = len(sh.inputs)
     # argument tuples are built once: the timed loop is one ctypes call per step
-    slot_args = [[(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.bf.data_ptr(), 14000, n_local,
-                   o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(),
-                   o.clock_idx.data_ptr(), o.term_frame.data_ptr(), o.status.data_ptr(), sptr)
-                  for o in slots] for x in sh.inputs]
+    if sh.uniform_bf is not None:
+        fn = ctx.lib.afsk_demod_batch_uniform
+        slot_args = [[(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.uniform_bf, 14000, n_local,
+                       o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(),
+                       o.clock_idx.data_ptr(), o.term_frame.data_ptr(), o.status.data_ptr(), None, None, 0, sptr)
+                      for o in slots] for x in sh.inputs]
+    else:
+        fn = ctx.lib.afsk_demod_batch
+        slot_args = [[(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.bf.data_ptr(), 14000, n_local,
+                       o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(),
+                       o.clock_idx.data_ptr(), o.term_frame.data_ptr(), o.status.data_ptr(), sptr)
+                      for o in slots] for x in sh.inputs]
 
     def launch(i: int) -> None:
         rc = fn(*slot_args[i % nin][i % nslots])
@@ -345,29 +403,55 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     torch.cuda.synchronize()
     if comm is not None:
         comm.synchronize()
-    out_all.zero_()            # a correct slot after the timed region was written BY the timed region
-    for gr in range(ngroups):
-        gathered_once[gr] = False
-    ctx.fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    state["timing"] = True
-    t0 = time.perf_counter()
-    ev0.record(cur)
-    for i in range(steps):
-        step(i)
-    finish(steps)
-    ev1.record(cur)
-    host_issue_s = time.perf_counter() - t0        # host time to enqueue the whole timed region
-    ctx.fence()
-    elapsed = time.perf_counter() - t0
-    event_ms = ev0.elapsed_time(ev1)
-    kernel_ms = event_ms / max(steps, 1)           # avg launch duration incl. any gaps
-    if ctx.use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev)
-        ctx.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
-    # ---- which step gets the full check: a random one among those whose slot still holds it
+    # HIP events inside the region: one per `eg` steps (every step when a step is >= ~200 us), so the
+    # records themselves cannot open gaps between 60 us kernels
+    eg = max(1, min(steps, int(-(-200e-6 // est_step_s)))) if steps > 0 else 1
+    region_s: list = []          # wall clock of each region (max over ranks)
+    region_event_ms: list = []   # HIP-event time of each region on this rank
+    interval_ms: list = []       # HIP-event time per step of every eg-step interval
+    host_issue_s = 0.0
+    n_regions = 1
+    r = 0
+    while r < n_regions:
+        out_all.zero_()            # a correct slot after a timed region was written BY that region
+        for gr in range(ngroups):
+            gathered_once[gr] = False
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps // eg + 2)]
+        ctx.fence()
+        state["timing"] = True
+        t0 = time.perf_counter()
+        marks[0].record(cur)
+        nm = 1
+        for i in range(steps):
+            step(i)
+            if (i + 1) % eg == 0 and i + 1 < steps:
+                marks[nm].record(cur)
+                nm += 1
+        finish(steps)
+        marks[nm].record(cur)
+        host_issue_s = time.perf_counter() - t0        # host time to enqueue the whole timed region
+        ctx.fence()
+        elapsed = time.perf_counter() - t0
+        state["timing"] = False
+        if ctx.use_dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev)
+            ctx.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())              # identical on every rank from here on
+        region_s.append(elapsed)
+        region_event_ms.append(marks[0].elapsed_time(marks[nm]))
+        for k in range(nm):
+            n_in = eg if k + 1 < nm else steps - eg * (nm - 1)
+            if n_in > 0:
+                interval_ms.append(marks[k].elapsed_time(marks[k + 1]) / n_in)
+        if r == 0 and steps > 0 and min_region_ms > 0:
+            n_regions = max(1, min(max_regions, int(-(-min_region_ms * 1e-3 // max(elapsed, 1e-6)))))
+        r += 1
+    elapsed = median(region_s)
+    event_ms = sum(region_event_ms)
+    kernel_ms = event_ms / max(steps * n_regions, 1)   # avg launch duration incl. any gaps, all regions
+
+    # ---- which step gets the full check: a random one among those whose slot still holds it (last region)
     lo = max(0, steps - nslots)
     chk_step = random.SystemRandom().randrange(lo, steps) if steps > 0 else 0
     chk = slots[chk_step % nslots]
@@ -388,22 +472,34 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     alg_bytes = int(2 * active.sum()) + out_bytes_alg
     achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
     samples_per_step = sh.n_total * STREAM_LEN
+    ev_med = median(interval_ms)
     rec = {
         "workload": sh.desc,
         "streams_per_gpu": n_local,
+        "entry": "afsk_demod_batch_uniform" if sh.uniform_bf is not None else "afsk_demod_batch",
         "steps": steps, "warmup": warmup, "preroll_launches": preroll_launches,
-        "value": round(samples_per_step * steps / elapsed / 1e6, 1),            # wall clock, fences included
-        "value_event_time": round(samples_per_step * steps / (event_ms * 1e-3) / 1e6, 1),   # HIP events
+        "value": round(samples_per_step * steps / elapsed / 1e6, 1),            # wall clock of the median region, fences included
+        "value_event_time": round(samples_per_step * steps * n_regions / (event_ms * 1e-3) / 1e6, 1),   # HIP events, all regions
         # the same wall-clock rate counting only the samples the reference has to read (up to the
         # squelch-triggering symbol); `value` counts every sample of the buffers, tail silence included
         "value_active_samples": round(float(active.sum()) * ctx.world * steps / elapsed / 1e6, 1),
         "unit": "Msamples/s",
         "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 5),
+        "timed_regions": n_regions,
+        "timed_region_ms": round(elapsed * 1e3, 4),
+        "timed_region_ms_all": [round(x * 1e3, 4) for x in region_s],
+        "timed_ms_total": round(sum(region_s) * 1e3, 3),
+        "event_ms_per_step_median": None if ev_med is None else round(ev_med, 5),
+        "event_intervals": {"count": len(interval_ms), "steps_per_interval": eg,
+                            "min_ms_per_step": round(min(interval_ms), 5) if interval_ms else None,
+                            "max_ms_per_step": round(max(interval_ms), 5) if interval_ms else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                      "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms": round(kernel_ms, 5),
+                     "kernel_ms_median": None if ev_med is None else round(ev_med, 5),
+                     "frac_at_median": None if ev_med is None else round(alg_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "full_buffer_gbs": round((2 * n_local * STREAM_LEN) / (kernel_ms * 1e-3) / 1e9, 1)},
         "input_buffers_rotated": nin,
         "roundtrip_match_rate": roundtrip_rate,
@@ -425,13 +521,13 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
         ctx.all_gather(sums, own)
         k_last = (steps - 1) % G
         per_rank = []
-        for r in range(world):
-            part = gbuf[r * G * flat_sz: (r + 1) * G * flat_sz]
-            ok_sum = bool((weighted_sum(torch, part) == sums[r]).item())
+        for rr in range(world):
+            part = gbuf[rr * G * flat_sz: (rr + 1) * G * flat_sz]
+            ok_sum = bool((weighted_sum(torch, part) == sums[rr]).item())
             v = batch.views_of_flat(part[k_last * flat_sz: (k_last + 1) * flat_sz], n_local, stride)
             ok_pay = None
             if sh.snr_db is None:
-                _, plen_r, payload_r, _ = Shard.host_meta(r * n_local, n_local, sh.bauds)
+                _, plen_r, payload_r, _ = Shard.host_meta(rr * n_local, n_local, sh.bauds)
                 pl = ctx.t(plen_r)
                 exp = ctx.t(payload_r)
                 width = min(int(exp.shape[1]), stride)
@@ -537,6 +633,238 @@ def attach_traffic(rec: dict, name: str, n_local: int, src_hash: str) -> None:
                             f"({src_hash}) on another run: {ent.get('source')}; not measured in this run")
 
 
+def event_timed(torch, stream, launch, reps: int, warm: int = 3):
+    """reps launches on `stream`, one HIP-event interval per launch -> (avg_ms, median_ms, all)."""
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    marks[0].record(stream)
+    for k in range(reps):
+        launch()
+        marks[k + 1].record(stream)
+    torch.cuda.synchronize()
+    ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(reps)]
+    return sum(ms) / len(ms), median(ms), ms
+
+
+def roofline_obj(alg_bytes: int, avg_ms: float, med_ms: float, bound: str = "hbm", peak: float = HBM_PEAK_GBS) -> dict:
+    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+    return {"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "GB/s",
+            "frac": round(ach / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "kernel_ms": round(avg_ms, 5), "kernel_ms_median": round(med_ms, 5),
+            "frac_at_median": round(alg_bytes / (med_ms * 1e-3) / 1e9 / peak, 4)}
+
+
+def measure_modulate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dict:
+    """the on-device modulator (Transmitter.__getFrames ref:452-469 + ECC.encode
+    ref:166-175 + the .wav writer quirk ref:239-244) re-writing the shard's whole input buffer.
+    Write-bound: 2 B per sample out (+ the payload bytes and 24 B of per-stream metadata in)."""
+    from afskmodem_amd import _native
+    torch = ctx.torch
+    x = sh.inputs[0]
+    sptr = C.c_void_p(ctx.cur.cuda_stream)
+    quirk = 0 if 12000 in sh.bauds else 1
+    args_ = (sh._payload_d.data_ptr(), int(sh._payload_d.shape[1]), sh._plen_d.data_ptr(), sh.bf.data_ptr(),
+             sh._ts_d.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), STREAM_LEN, sh.n_local, quirk, x.data_ptr(), sptr)
+
+    def launch():
+        rc = ctx.lib.afsk_modulate_batch(*args_)
+        if rc != 0:
+            _native.check(rc)
+
+    x.zero_()
+    avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
+    alg = 2 * sh.n_local * STREAM_LEN + int(sh.plen_h.sum()) + 24 * sh.n_local
+    rec = {"row": "f1 on-device modulator (afsk_modulate_batch)", "streams": sh.n_local, "stream_len": STREAM_LEN,
+           "bauds": list(sh.bauds), "launches": reps, "unit": "Msamples/s",
+           "value": round(sh.n_local * STREAM_LEN / (avg * 1e-3) / 1e6, 1),
+           "roofline": roofline_obj(alg, avg, med)}
+    rec["roofline"]["bound_note"] = "HBM WRITE bound: 2 B per sample stored once"
+    if not ctx.args.no_cpu_baseline:
+        from oracle import afsk_oracle as O   # checker only, after the timed launches
+        ns = min(check_streams, sh.n_local)
+        got = x[: ns * STREAM_LEN].cpu().numpy().reshape(ns, STREAM_LEN)
+        want = O.modulate_batch(sh.payload_h[:ns], sh.plen_h[:ns], sh.bf_h[:ns],
+                                np.asarray([int(t) for t in sh._ts_d[:ns].cpu().numpy()], np.int32),
+                                np.arange(ns, dtype=np.int64) * STREAM_LEN, np.full(ns, STREAM_LEN, np.int32),
+                                ns * STREAM_LEN, bool(quirk)).reshape(ns, STREAM_LEN)
+        rec["oracle_match_rate"] = float((got == want).all(axis=1).mean())
+        rec["oracle_sample_streams"] = ns
+    return rec
+
+
+def measure_gate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dict:
+    """live-gate replay (Receiver.__listen ref:299-319: 2048-frame block amplitudes,
+    start > 18000, stop < 14000) over the shard's streams as captures.  Read-bound: 2 B per sample of
+    every whole 2048-frame block in (+ 4 B per block and 12 B per capture out)."""
+    from afskmodem_amd import _native
+    torch = ctx.torch
+    n = sh.n_local
+    max_blocks, max_bursts = STREAM_LEN // 2048, 4
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=ctx.dev)  # noqa: E731
+    amp, nb, bs, bl, oe = i32(n, max_blocks), i32(n), i32(n, max_bursts), i32(n, max_bursts), i32(n)
+    sptr = C.c_void_p(ctx.cur.cuda_stream)
+    nin = len(sh.inputs)
+    calls = [(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), STREAM_LEN, 18000, 14000, n, max_bursts,
+              amp.data_ptr(), nb.data_ptr(), bs.data_ptr(), bl.data_ptr(), oe.data_ptr(), sptr) for x in sh.inputs]
+    k = [0]
+
+    def launch():
+        rc = ctx.lib.afsk_gate_batch(*calls[k[0] % nin])
+        k[0] += 1
+        if rc != 0:
+            _native.check(rc)
+
+    avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
+    alg = 2 * n * max_blocks * 2048 + 4 * n * max_blocks + 12 * n
+    rec = {"row": "f2 live-gate replay (afsk_gate_batch: block amplitudes + burst scan)", "captures": n,
+           "capture_len": STREAM_LEN, "launches": reps, "input_buffers_rotated": nin, "unit": "Msamples/s",
+           "value": round(n * STREAM_LEN / (avg * 1e-3) / 1e6, 1),
+           "bursts_found": int(nb.sum().item()),
+           "roofline": roofline_obj(alg, avg, med)}
+    if not ctx.args.no_cpu_baseline:
+        from oracle import afsk_oracle as O   # checker only
+        ns = min(check_streams, n)
+        h = sh.inputs[(k[0] - 1) % nin][: ns * STREAM_LEN].cpu().numpy().reshape(ns, STREAM_LEN)
+        g_nb, g_bs, g_bl, g_oe = (t[:ns].cpu().numpy() for t in (nb, bs, bl, oe))
+        ok = 0
+        for i in range(ns):
+            bursts, open_end = O.gate_stream(h[i], 18000, 14000, max_bursts)
+            k_ = int(g_nb[i])
+            ok += bool(len(bursts) == k_ and open_end == int(g_oe[i])
+                       and bursts == [(int(g_bs[i, j]), int(g_bl[i, j])) for j in range(k_)])
+        rec["oracle_match_rate"] = ok / ns
+        rec["oracle_sample_streams"] = ns
+    return rec
+
+
+def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
+    """n .wav files (SoundInput.loadFromFile ref:213-217) -> the stream-major
+    device layout (afsk_wav_probe + afsk_wav_upload), then decoded by Receiver.load_batch.
+    PCIe-bound: measured against ONE pinned hipMemcpy of the same byte count on this box."""
+    import shutil
+    import tempfile
+    import afskmodem_amd as afskmodem
+    from afskmodem_amd import batch
+    torch = ctx.torch
+    afskmodem.LOG_LEVEL = 5
+    d = tempfile.mkdtemp(prefix="afsk_bench_wavs_")
+    try:
+        t = afskmodem.Transmitter(1200)
+        payloads = [bytes([48 + i]) * 34 for i in range(16)]
+        for i, pl in enumerate(payloads):
+            t.save(pl, os.path.join(d, f"seed{i}.wav"))
+        names = []
+        for i in range(n_files):
+            fn = os.path.join(d, f"f{i:05d}.wav")
+            shutil.copyfile(os.path.join(d, f"seed{i % 16}.wav"), fn)
+            names.append(fn)
+        total_bytes = sum(os.path.getsize(f) for f in names)
+
+        def timed(fn_):
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn_()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return ts
+
+        batch.load_wav_batch(names[:64], ctx.dev)                  # warm: library, pinned windows
+        ing = timed(lambda: batch.load_wav_batch(names, ctx.dev))
+        pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
+        devbuf = torch.empty(total_bytes // 2, dtype=torch.int16, device=ctx.dev)
+        devbuf.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        pc = timed(lambda: devbuf.copy_(pin, non_blocking=True))
+        rx = afskmodem.Receiver(1200)
+        e2e = timed(lambda: rx.load_batch(names, string=False))
+        decoded = rx.load_batch(names, string=False)
+        ok = sum(decoded[i] == payloads[i % 16] for i in range(n_files))
+        avg, med = sum(ing) / len(ing), median(ing)
+        peak = total_bytes / min(pc) / 1e9
+        rec = {"row": "f3 .wav ingest (afsk_wav_probe + afsk_wav_upload)", "files": n_files,
+               "bytes": total_bytes, "reps": reps, "unit": "files/s", "value": round(n_files / med),
+               "ingest_ms": {"median": round(med * 1e3, 3), "best": round(min(ing) * 1e3, 3)},
+               "pinned_hipMemcpy_ms": round(min(pc) * 1e3, 3),
+               "load_batch_end_to_end_ms": {"median": round(median(e2e) * 1e3, 3), "best": round(min(e2e) * 1e3, 3)},
+               "decoded_match_rate": ok / n_files,
+               "roofline": {"bound": "pcie", "achieved": round(total_bytes / avg / 1e9, 2), "peak": round(peak, 2),
+                            "unit": "GB/s", "frac": round(total_bytes / avg / 1e9 / peak, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(avg * 1e3, 3),
+                            "kernel_ms_median": round(med * 1e3, 3),
+                            "frac_at_median": round(total_bytes / med / 1e9 / peak, 4),
+                            "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
+                                          "run (best of %d); the ingest also opens, probes, preads and closes every file "
+                                          "(page cache warm: the files were just written)" % reps},
+               "host_cores": os.cpu_count(), "files_on": d.split(os.sep)[1] if os.sep in d else d}
+        del pin, devbuf
+        return rec
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s: float = 10.0, idx=None, label=""):
+    """The CPU oracle (C port of the reference hot path) timed on this box's host cores on a bounded
+    sample of the shard (the first ns streams, or the streams listed in idx), checked against the GPU's
+    outputs first; plus the pure-Python 'reference-shaped' restatement on one core."""
+    from oracle import afsk_oracle as O   # checker + reported CPU baseline only
+    from oracle import pyref
+    if idx is None:
+        idx = np.arange(ns)
+    idx = np.asarray(idx[:ns], dtype=np.int64)
+    ns = int(idx.size)
+    x = sh.inputs[0].view(sh.n_local, STREAM_LEN)
+    h = x[sh.ctx.torch.from_numpy(idx).to(x.device)].cpu().numpy().reshape(-1)
+    h_off = np.arange(ns, dtype=np.int64) * STREAM_LEN
+    h_ln = np.full(ns, STREAM_LEN, np.int32)
+    bf = np.ascontiguousarray(sh.bf_h[idx])
+    want = O.demod_batch(h, h_off, h_ln, bf, 14000, out_stride=sh.stride, n_threads=cores)
+    match = 0
+    for j, s_i in enumerate(idx):
+        nb = int(want["nbytes"][j])
+        m = min(nb, sh.stride)
+        match += bool(nb == int(res.nbytes[s_i]) and int(want["nbits"][j]) == int(res.nbits[s_i])
+                      and int(want["clock_idx"][j]) == int(res.clock_idx[s_i])
+                      and int(want["term_frame"][j]) == int(res.term_frame[s_i])
+                      and want["bytes"][j, :m].tobytes() == got_payloads[s_i][:m])
+    n1 = max(ns // 8, 1)
+    t1 = time.perf_counter()
+    O.demod_batch(h[: n1 * STREAM_LEN], h_off[:n1], h_ln[:n1], bf[:n1], 14000, out_stride=sh.stride, n_threads=1)
+    dt1 = time.perf_counter() - t1
+    reps = 0
+    t2 = time.perf_counter()
+    while True:
+        O.demod_batch(h, h_off, h_ln, bf, 14000, out_stride=sh.stride, n_threads=cores)
+        reps += 1
+        if time.perf_counter() - t2 > budget_s or reps >= 50:
+            break
+    dtc = (time.perf_counter() - t2) / reps
+    # "reference-shaped" figure: the pure-Python restatement (oracle/pyref.py) on one core;
+    # in the dev container it runs at 1.01-1.07x the speed of the real afskmodem.py.
+    npy = min(3, ns)
+    t3 = time.perf_counter()
+    for j in range(npy):
+        data, _, _, _ = pyref.demod(h[j * STREAM_LEN: (j + 1) * STREAM_LEN].tolist(), int(bf[j]))
+        assert data == got_payloads[int(idx[j])], "pure-Python restatement disagrees with the GPU"
+    dtp = (time.perf_counter() - t3) / npy
+    doc = {
+        "value": round(ns * STREAM_LEN / dtc / 1e6, 1), "unit": "Msamples/s", "cores": cores,
+        "kind": "port",
+        "sample": f"{ns} streams of the same batch{label}, CPU oracle (C port of afskmodem.py hot path), "
+                  f"{cores} threads, {reps} reps; single thread on {n1} streams: "
+                  f"{round(n1 * STREAM_LEN / dt1 / 1e6, 1)} Msamples/s",
+        "single_thread_value": round(n1 * STREAM_LEN / dt1 / 1e6, 1),
+        "python_reference_shaped_value": round(STREAM_LEN / dtp / 1e6, 3),
+        "python_reference_shaped_note": "oracle/pyref.py (pure-Python restatement, CPython, 1 core, "
+                                        f"{npy} streams); calibrated at 1.01-1.07x the real reference's "
+                                        "speed in the dev container (DESIGN.md 4.3); the real afskmodem.py "
+                                        "(1.3 Msamples/s/core at 1200 baud) was only ever timed in the build container",
+    }
+    return doc, match / ns, ns
+
+
 def run_rank(args) -> None:
     ctx = Ctx(args)
     torch, dist = ctx.torch, ctx.dist
@@ -544,23 +872,15 @@ def run_rank(args) -> None:
     cores = os.cpu_count() or 1
     src_hash = kernel_source_hash()
 
-    main_name = args.workload or ("config2" if world == 1 else "config5")
-    if args.sub is not None:
-        sub_names = [s for s in args.sub.split(",") if s]
-    elif args.workload or args.streams:
-        sub_names = []
-    else:
-        sub_names = ["config3", "config4", "config5"] if world == 1 else ["config2"]
-    for s in [main_name] + sub_names:
-        if s not in WORKLOADS:
-            raise SystemExit(f"unknown workload {s}")
+    pl = plan(world, args.workload, args.sub, args.streams)
+    main_name, sub_names, next_rows = pl["main"], pl["subs"], pl["next"]
 
     def n_for(name: str) -> int:
         return args.streams if args.streams > 0 else WORKLOADS[name][0]
 
     # ---------------- main record
     sh = Shard(ctx, main_name, n_for(main_name))
-    rec, aux = measure(ctx, sh, args.steps, args.warmup, args.preroll_ms, args.gather_every)
+    rec, aux = measure(ctx, sh, args.steps, args.warmup, args.preroll_ms, args.gather_every, args.min_region_ms)
     attach_traffic(rec, main_name, sh.n_local, src_hash)
     out = {
         "metric": METRIC,
@@ -576,11 +896,14 @@ def run_rank(args) -> None:
         "vs_baseline": None,
         "dtype": "int16",
         "data": "synthetic",
-        "config": {"workload": sh.desc, "streams_per_gpu": sh.n_local, "streams_total": sh.n_total,
-                   "stream_len": STREAM_LEN, "bauds": list(sh.bauds), "snr_db": sh.snr_db,
-                   "parallelism": f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")
-                                  + (" [DIAGNOSTIC: gloo backend" + (", all ranks on one GPU" if args.share_gpu0 else "") + "]"
-                                     if ctx.backend != "nccl" else "")},
+        "config": config_block(main_name, sh.n_local, world, ctx.backend, args.share_gpu0),
+        "entry": rec["entry"],
+        "timed_regions": rec["timed_regions"],
+        "timed_region_ms": rec["timed_region_ms"],
+        "timed_region_ms_all": rec["timed_region_ms_all"],
+        "timed_ms_total": rec["timed_ms_total"],
+        "event_ms_per_step_median": rec["event_ms_per_step_median"],
+        "event_intervals": rec["event_intervals"],
         "value_event_time": rec["value_event_time"],
         "value_active_samples": rec["value_active_samples"],
         "roofline": rec["roofline"],
@@ -591,86 +914,67 @@ def run_rank(args) -> None:
         "all_timed_steps_identical": rec["all_timed_steps_identical"],
         "host_issue_ms_per_step": rec["host_issue_ms_per_step"],
     }
+    out["config"]["bauds"] = list(sh.bauds)       # (--workload custom --bauds ... replaces the table entry)
     for k in ("ranks_seen", "gather_check", "gather_check_on_every_rank", "gather_every_steps",
               "gathers_in_timed_region", "gather_ms"):
         if k in rec:
             out[k] = rec[k]
 
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import afsk_oracle as O   # checker + reported CPU baseline only
-        res, got_payloads = aux["res"], aux["got_payloads"]
         ns = args.cpu_sample_streams or min(sh.n_local, 4096)
-        rate, _, (h, h_off, h_ln) = oracle_match(sh, res, got_payloads, sh.inputs[0], ns, cores)
-        n1 = max(ns // 8, 1)
-        t1 = time.perf_counter()
-        O.demod_batch(h[: n1 * STREAM_LEN], h_off[:n1], h_ln[:n1], sh.bf_h[:n1], 14000,
-                      out_stride=sh.stride, n_threads=1)
-        dt1 = time.perf_counter() - t1
-        reps = 0
-        t2 = time.perf_counter()
-        while True:
-            O.demod_batch(h, h_off, h_ln, sh.bf_h[:ns], 14000, out_stride=sh.stride, n_threads=cores)
-            reps += 1
-            if time.perf_counter() - t2 > 10.0 or reps >= 50:
-                break
-        dtc = (time.perf_counter() - t2) / reps
-        # "reference-shaped" figure: the pure-Python restatement (oracle/pyref.py) on one core;
-        # in the dev container it runs at 1.01-1.07x the speed of the real afskmodem.py.
-        from oracle import pyref
-        npy = 3
-        t3 = time.perf_counter()
-        for s_i in range(npy):
-            data, _, _, _ = pyref.demod(h[s_i * STREAM_LEN: (s_i + 1) * STREAM_LEN].tolist(), int(sh.bf_h[s_i]))
-            assert data == got_payloads[s_i], "pure-Python restatement disagrees with the GPU"
-        dtp = (time.perf_counter() - t3) / npy
-        out["cpu_baseline"] = {
-            "value": round(ns * STREAM_LEN / dtc / 1e6, 1), "unit": "Msamples/s", "cores": cores,
-            "kind": "port",
-            "sample": f"first {ns} streams of the same batch, CPU oracle (C port of afskmodem.py hot path), "
-                      f"{cores} threads, {reps} reps; single thread on {n1} streams: "
-                      f"{round(n1 * STREAM_LEN / dt1 / 1e6, 1)} Msamples/s",
-            "single_thread_value": round(n1 * STREAM_LEN / dt1 / 1e6, 1),
-            "python_reference_shaped_value": round(STREAM_LEN / dtp / 1e6, 3),
-            "python_reference_shaped_note": "oracle/pyref.py (pure-Python restatement, CPython, 1 core, "
-                                            f"{npy} streams); calibrated at 1.01-1.07x the real reference's "
-                                            "speed in the dev container (DESIGN.md 4.3); the real afskmodem.py "
-                                            "(1.3 Msamples/s/core) was only ever timed in the build container",
-        }
-        out["match_rate"] = rate
-        out["match_sample_streams"] = ns
-        del h
+        out["cpu_baseline"], out["match_rate"], out["match_sample_streams"] = cpu_baseline_for(
+            sh, aux["res"], aux["got_payloads"], ns, cores, 10.0, label=" (the first of them)")
+    subs = {}
+    # the next rows that reuse the headline shard's buffers: f1 re-writes its input, f2 reads it
+    if world == 1 and "f1_modulate" in next_rows:
+        subs["f1_modulate"] = measure_modulate(ctx, sh, args.next_reps)
+    if world == 1 and "f2_gate" in next_rows:
+        subs["f2_gate"] = {"captures_%d" % sh.n_local: measure_gate(ctx, sh, args.next_reps)}
     del sh, aux
     torch.cuda.empty_cache()
 
     # ---------------- sub-records: the other single-GPU configs in the same line
     per_workload = {main_name: out["value"]}
-    subs = {}
     for name in sub_names:
-        if name == main_name:
-            continue
         n_local = n_for(name)
         big = n_local * STREAM_LEN * 2 >= (1 << 30)
         s_steps = args.sub_steps or (20 if big else 200)
         s_warm = 3 if big else 20
         shs = Shard(ctx, name, n_local)
-        srec, saux = measure(ctx, shs, s_steps, s_warm, min(args.preroll_ms, 100.0), args.gather_every)
+        srec, saux = measure(ctx, shs, s_steps, s_warm, min(args.preroll_ms, 100.0), args.gather_every, args.min_region_ms)
         attach_traffic(srec, name, n_local, src_hash)
         if world == 1 and not args.no_cpu_baseline:
             ns = min(n_local, args.sub_cpu_sample)
             srec["match_rate"], _, _ = oracle_match(shs, saux["res"], saux["got_payloads"], shs.inputs[0], ns, cores)
             srec["match_sample_streams"] = ns
+            if len(set(shs.bauds)) > 1:
+                # a CPU figure per baud share: the reference is 2.8x slower per sample at 300 baud and
+                # 1.4x faster at 2400 baud than at 1200 (the sync search costs (4096 - 2bf) * 2bf)
+                by = {}
+                for b_ in sorted(set(shs.bauds)):
+                    idx = np.nonzero(shs.bf_h == 48000 // b_)[0]
+                    doc, rate, nn = cpu_baseline_for(shs, saux["res"], saux["got_payloads"], min(ns, idx.size), cores,
+                                                     3.0, idx=idx, label=f" (the first {b_}-baud streams)")
+                    doc["match_rate"], doc["streams"] = rate, nn
+                    by[str(b_)] = doc
+                srec["cpu_baseline_by_baud"] = by
             if name == "config4":
                 srec["ber_curve"] = ber_curve(ctx, shs, ns, cores)
+                shs.regenerate(shs.snr_db)
+        if world == 1 and "f2_gate" in next_rows and name == "config2":
+            subs.setdefault("f2_gate", {})["captures_%d" % n_local] = measure_gate(ctx, shs, max(args.next_reps, 50))
         per_workload[name] = srec["value"]
         subs[name] = srec
         del shs, saux
         torch.cuda.empty_cache()
+    if world == 1 and "f3_wav_ingest" in next_rows:
+        subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
-    out["scaling_note"] = ("headline workload: config2 (4096 streams/GPU) at N = 1, config5 (65536 streams/GPU, the shard "
-                           "north_star names) at N > 1; every line carries both in per_workload_value, so each "
-                           "weak-scaling curve has its own 1-GPU point (config5's is per_workload_value.config5 of the N = 1 line)")
+    out["scaling_note"] = ("the headline workload is the config5 shard (65536 streams x 1 s @1200 baud per GPU, what north_star "
+                           "names) at EVERY N: value(N) / (N * value(1)) is the weak-scaling efficiency; config2 / config3 / "
+                           "config4 and the SURVEY 8(f) rows f1 / f2 / f3 ride along as sub_records at N = 1, the config2 shard at N > 1")
     if ctx.use_dist:
         dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit,
@@ -689,9 +993,15 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
-                    help="headline workload (default: config2 at N = 1, config5 at N > 1); "
+                    help="headline workload (default: config5 at every N); "
                          "giving one explicitly drops the sub-records unless --sub lists them")
-    ap.add_argument("--sub", default=None, help="comma list of sub-record workloads ('' = none)")
+    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest ('' = none)")
+    ap.add_argument("--min-region-ms", type=float, default=50.0,
+                    help="repeat the K-step timed region until the regions add up to this (0 = exactly one region)")
+    ap.add_argument("--entry", default="auto", choices=["auto", "mixed"],
+                    help="auto = one-rate shards use afsk_demod_batch_uniform; mixed = always the per-stream entry (A/B)")
+    ap.add_argument("--next-reps", type=int, default=20, help="timed launches of the f1 / f2 sub-records")
+    ap.add_argument("--wav-files", type=int, default=4096, help="files of the f3_wav_ingest sub-record")
     ap.add_argument("--sub-steps", type=int, default=0, help="timed steps of every sub-record (0 = 20 / 200)")
     ap.add_argument("--sub-cpu-sample", type=int, default=1024,
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")

@@ -114,13 +114,32 @@ int afsk_demod_batch_ex(const int16_t *samples, const int64_t *stream_offset,
                         void *hip_stream);
 
 /*
+ * The Receiver-shaped form of afsk_demod_batch_ex: ONE bit_frames for every stream of the
+ * launch, passed by value.  A Receiver has exactly one baud rate (Receiver.__init__ :275-284:
+ * bit_frames, the two tone templates and the training cycle are per-object constants), so a batch
+ * decoded on behalf of one Receiver never needs the per-stream array.  bit_frames is validated on
+ * the host (AFSK_E_INVALID_BAUD) and selects a kernel compiled for exactly that geometry -- no
+ * per-stream load of it, no geometry switch in the kernel.  Same outputs, bit for bit, as
+ * afsk_demod_batch_ex with bit_frames[s] == bit_frames for all s; out_corrected / out_margins may
+ * be NULL (margin_stride 0).
+ */
+int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offset,
+                             const int32_t *stream_len, int32_t bit_frames,
+                             int32_t amp_end_threshold, int32_t n_streams, uint8_t *out_bytes,
+                             int32_t out_stride, int32_t *out_nbytes, int32_t *out_nbits,
+                             int32_t *out_clock_idx, int32_t *out_term_frame, int32_t *out_status,
+                             int32_t *out_corrected, int32_t *out_margins, int32_t margin_stride,
+                             void *hip_stream);
+
+/*
  * Same operation on HOST buffers: allocates device scratch, copies in, runs the
  * HIP kernel, copies out, synchronises.  This is the PCIe-inclusive convenience
  * path a single Receiver.load() uses; it is not the benchmarked entry.
  * Both host entries work on a private NON-BLOCKING HIP stream of the calling thread (never the
  * NULL stream): they do not synchronise with the caller's own streams or with calls made by
  * other threads, and may be called concurrently (the reference's Receivers are independent
- * objects, afskmodem.py:275-284).  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
+ * objects, afskmodem.py:275-284).  When every bit_frames[s] holds the same value (the host can see
+ * that here) they launch the uniform kernel of afsk_demod_batch_uniform.  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
  */
 int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           const int64_t *stream_offset, const int32_t *stream_len,
@@ -170,7 +189,13 @@ int afsk_host_scratch_release(void);
  *   memory, a few threads in parallel) and sends each window to
  *   d_samples[stream_offset[s] ..] while the next one is being filled.  stream_offset is in
  *   samples, ascending, streams must not overlap and must fit capacity_samples.  Synchronous for
- *   the caller, on the calling thread's private non-blocking stream.
+ *   the caller, on the calling thread's private non-blocking stream (NOT ordered against the
+ *   caller's own streams: work of the caller that still reads or writes the destination range
+ *   must have completed before the call).  Device bytes written: the streams themselves, plus
+ *   gaps of at most 256 bytes BETWEEN two consecutive streams (alignment padding), which are set
+ *   to zero; a larger gap between two streams and everything outside the streams is not touched,
+ *   so one buffer can be filled by several calls.  afsk_wav_probe is host-only and, like
+ *   afsk_wav_upload's file reading, fork-safe (a forked child builds its own I/O thread pool).
  */
 #define AFSK_WAV_OK 0
 #define AFSK_WAV_IO 1          /* cannot open / read                                      */

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "perf: wall-time guards on a GPU box (run with -m perf; not part of the parity suite)")
 
 
 def pytest_sessionstart(session):

@@ -54,3 +54,38 @@ def test_kernel_source_hash_is_stable_and_sensitive(tmp_path):
     import bench
     h = bench.kernel_source_hash()
     assert h == bench.kernel_source_hash() and len(h) == 16
+
+
+def test_headline_workload_is_the_same_at_every_n():
+    """One weak-scaling curve: the N = 1 and the N > 1 lines name the same workload (the config5
+    shard, BASELINE.json configs[4] per GPU); only what rides along differs."""
+    import bench
+    blocks = {}
+    for world in (1, 2, 4, 8):
+        pl = bench.plan(world)
+        assert pl["main"] == bench.HEADLINE == "config5"
+        cb = bench.config_block(pl["main"], bench.WORKLOADS[pl["main"]][0], world)
+        assert cb["workload"].startswith("configs[4]") and cb["streams_per_gpu"] == 65536
+        assert cb["streams_total"] == 65536 * world and cb["bauds"] == [1200]
+        blocks[world] = cb
+    assert blocks[1]["workload"] == blocks[2]["workload"] == blocks[8]["workload"]
+    assert blocks[8]["streams_total"] == 524288
+    one, two = bench.plan(1), bench.plan(2)
+    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS)
+    assert two["subs"] == ["config2"] and two["next"] == []
+    # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline
+    assert bench.plan(1, "config2") == {"main": "config2", "subs": [], "next": []}
+    assert bench.plan(1, "custom", "config3,f2_gate") == {"main": "custom", "subs": ["config3"], "next": ["f2_gate"]}
+    with pytest.raises(SystemExit):
+        bench.plan(1, "f1_modulate")
+    with pytest.raises(SystemExit):
+        bench.plan(1, "", "nonsense")
+
+
+def test_stub_rank_line_names_the_headline_workload():
+    """The relayed N = 2 line and bench.plan(1) agree on the workload name."""
+    import bench
+    rc, out = _launch("ok")
+    assert rc == 0
+    doc = json.loads([ln for ln in out.splitlines() if ln.strip()][0])
+    assert doc["config"]["workload"] == bench.config_block(bench.plan(1)["main"], 65536, 1)["workload"]

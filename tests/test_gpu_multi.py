@@ -63,7 +63,10 @@ def _rank_main(rank, world, port, n_total, q):
         stride = batch.out_stride_for(L, 20)
         res = batch.alloc_result(n, stride, dev)
         batch.demod_batch(x, off, ln, d_bf, 14000, out=res)
-        parts = adist.gather_flat(res, n_total)
+        equal = n_total % world == 0
+        # the general (ragged-shard) form: shards may differ by one stream -> padded rows, one collective
+        full = adist.gather_results(res, n_total)
+        parts = adist.gather_flat(res, n_total) if equal else None
         torch.cuda.synchronize()
         # the oracle decodes this rank's own inputs; the gathered slice of every OTHER rank is
         # checked by that rank's oracle result, exchanged as a second (checker-side) gather
@@ -73,17 +76,24 @@ def _rank_main(rank, world, port, n_total, q):
         for f in FIELDS:
             getattr(wflat, f).copy_(t(want[f]))
         wflat.bytes.copy_(t(want["bytes"][:, :stride]))
-        wparts = adist.gather_flat(wflat, n_total)
-        ok = len(parts) == world
-        for r in range(world):
-            g, w = parts[r], wparts[r]
-            for f in FIELDS:
-                ok = ok and bool(torch.equal(getattr(g, f), getattr(w, f)))
-            col = torch.arange(stride, device=dev)[None, :]
+        wfull = adist.gather_results(wflat, n_total)
+        col = torch.arange(stride, device=dev)[None, :]
+
+        def same(g, w):
+            r_ok = all(bool(torch.equal(getattr(g, f), getattr(w, f))) for f in FIELDS)
             m = col < torch.clamp(w.nbytes, max=stride)[:, None]
-            ok = ok and bool(((g.bytes == w.bytes) | ~m).all().item())
+            return r_ok and bool(((g.bytes == w.bytes) | ~m).all().item())
+
+        ok = int(full.nbytes.shape[0]) == n_total and same(full, wfull)
+        if equal:
+            wparts = adist.gather_flat(wflat, n_total)
+            ok = ok and len(parts) == world
+            for r in range(world):
+                ok = ok and same(parts[r], wparts[r])
+                rb, re_ = adist.shard_range(n_total, r, world)
+                ok = ok and all(bool(torch.equal(getattr(parts[r], f), getattr(full, f)[rb:re_])) for f in FIELDS)
         # clean streams of my shard decode to their payloads (not vacuous: the oracle agrees AND the data is right)
-        mine = parts[rank].cpu().payloads()
+        mine = batch.DemodResult(*(getattr(full, f)[b:e] for f in ("bytes",) + FIELDS)).cpu().payloads()
         clean_ok = all(mine[s] == payload[s, : plen[s]].tobytes() for s in range(n) if snr[s] > 30)
         q.put((rank, bool(ok), bool(clean_ok), int(ones.item()), ""))
         dist.destroy_process_group()
@@ -92,7 +102,8 @@ def _rank_main(rank, world, port, n_total, q):
         raise
 
 
-def test_two_rank_rccl_gather_matches_oracle():
+@pytest.mark.parametrize("n_total", [96, 97])
+def test_two_rank_rccl_gather_matches_oracle(n_total):
     import torch
     import torch.multiprocessing as mp
     from afskmodem_amd import _native
@@ -100,7 +111,7 @@ def test_two_rank_rccl_gather_matches_oracle():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box); 1-GPU boxes run "
                     "test_single_rank_rccl_gather_roundtrip instead")
-    world, n_total = 2, 96
+    world = 2                     # 97 streams: shards of 48 and 49 (dist.gather_results pads the rows)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -119,13 +130,15 @@ def test_two_rank_rccl_gather_matches_oracle():
         assert clean_ok, f"rank {rank}: clean streams did not decode to their payloads"
 
 
-def test_single_rank_rccl_gather_roundtrip():
+@pytest.mark.parametrize("n_total", [48, 49])
+def test_single_rank_rccl_gather_roundtrip(n_total):
     """1-GPU boxes: the same code path with a single-rank RCCL group (spawned, so the process
-    group never leaks into the pytest process)."""
+    group never leaks into the pytest process): gather_flat AND the general gather_results form
+    (pack -> all_gather_into_tensor over RCCL -> trim -> unpack) on device tensors."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rank_main, args=(0, 1, _free_port(), 48, q))
+    p = ctx.Process(target=_rank_main, args=(0, 1, _free_port(), n_total, q))
     p.start()
     rank, ok, clean_ok, seen, err = q.get(timeout=600)
     p.join(timeout=120)
@@ -175,3 +188,105 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert d["gather_check"] == [True, True] and d["gather_check_on_every_rank"] is True
     assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
     assert d["config"]["streams_total"] == 1536 and d["gathers_in_timed_region"] == 3
+
+
+def _ragged_rank(rank, world, port, n_total, q):
+    """Two ranks on ONE device (gloo group; RCCL refuses that): unequal shards through
+    dist.gather_results with the records staged through the host for the collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from afskmodem_amd import batch, synth
+    from afskmodem_amd import dist as adist
+    from oracle import afsk_oracle as O   # checker only
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        b, e = adist.shard_range(n_total, rank, world)
+        n = e - b
+        bf, plen, payload, ts, snr = _batch_meta(b, n)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        x = torch.empty(n * L, dtype=torch.int16, device=dev)
+        off, ln = batch.uniform_layout(n, L, dev)
+        d_bf = t(bf)
+        batch.modulate_batch(t(payload), t(plen), d_bf, t(ts), off, ln, L, x, True)
+        q24 = np.asarray([synth.snr_to_scale_q24(s) for s in snr], np.int32)
+        batch.add_noise_batch(x, off, ln, L, q24, seed=5, stream_idx_base=b)
+        stride = batch.out_stride_for(L, 20)
+        res = batch.demod_batch(x, off, ln, d_bf, 14000, out_stride=stride)
+        torch.cuda.synchronize()
+        host = batch.DemodResult(*(getattr(res, f).cpu() for f in ("bytes",) + FIELDS))
+        full = adist.gather_results(host, n_total)            # CPU tensors over gloo
+        # the whole batch, decoded by the oracle from the stream indices alone
+        bf_a, plen_a, payload_a, ts_a, snr_a = _batch_meta(0, n_total)
+        xs = O.modulate_batch(payload_a, plen_a, bf_a, ts_a, np.arange(n_total, dtype=np.int64) * L,
+                              np.full(n_total, L, np.int32), n_total * L, True)
+        for s_i in range(n_total):
+            xs[s_i * L: (s_i + 1) * L] = O.add_noise(xs[s_i * L: (s_i + 1) * L], 5, s_i, synth.snr_to_scale_q24(snr_a[s_i]))
+        want = O.demod_batch(xs, np.arange(n_total, dtype=np.int64) * L, np.full(n_total, L, np.int32), bf_a, 14000,
+                             out_stride=stride)
+        ok = int(full.nbytes.shape[0]) == n_total
+        for f in FIELDS:
+            ok = ok and bool(np.array_equal(getattr(full, f).numpy(), want[f]))
+        for s_i in range(n_total):
+            nb = min(int(want["nbytes"][s_i]), stride)
+            ok = ok and full.bytes[s_i, :nb].numpy().tobytes() == want["bytes"][s_i, :nb].tobytes()
+        q.put((rank, bool(ok), n, ""))
+        dist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, False, 0, repr(exc)))
+        raise
+
+
+def test_unequal_shards_two_ranks_on_one_gpu():
+    """n_total % world != 0 on real hardware: 2 ranks x (48 | 49) streams demodulated on device 0,
+    gathered with dist.gather_results; the covering result equals the oracle's decode of all 97."""
+    import torch.multiprocessing as mp
+    from afskmodem_amd import _native
+    assert _native.device_count() > 0, "no HIP device: GPU tests need an MI355X"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_rank, args=(r, 2, port, 97, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(g[2] for g in got) == [48, 49]
+    for rank, ok, n, err in got:
+        assert err == "" and ok, (rank, err)
+
+
+def test_bench_eight_rank_rehearsal_full_size_on_one_gpu():
+    """The driver's 8-GPU scaling run, rehearsed on ONE device at FULL SIZE: `python bench.py --gpus 8`
+    with the default 65536 streams x 1 s per rank (8 x 6.29 GB of inputs resident at once) plus the
+    config2 sub-record, reduced steps.  Launcher, 8 ranks, free port, gather_every grouping, per-rank
+    gather_check, ranks_seen 8, ONE JSON line, rc 0.  (Diagnostic gloo backend: RCCL refuses several
+    ranks on one device; throughput is meaningless by construction.)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+                        "--share-gpu0", "--steps", "5", "--warmup", "1", "--preroll-ms", "0", "--min-region-ms", "0",
+                        "--sub-steps", "8"],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8
+    assert d["gather_check"] == [True] * 8 and d["gather_check_on_every_rank"] is True
+    assert d["config"]["streams_per_gpu"] == 65536 and d["config"]["streams_total"] == 524288
+    assert d["config"]["workload"].startswith("configs[4]")
+    assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
+    sub = d["sub_records"]["config2"]
+    assert sub["ranks_seen"] == 8 and sub["gather_check"] == [True] * 8 and sub["roundtrip_match_rate"] == 1.0

@@ -25,6 +25,57 @@ def torch_cuda():
     return torch
 
 
+REAL_DEMOD_BATCH = batch.demod_batch
+
+
+@pytest.fixture(autouse=True, params=["mixed", "uniform"])
+def entry(request, monkeypatch):
+    """Every test of this file runs twice: once with every device launch forced through the
+    per-stream entry (afsk_demod_batch / _ex: the mixed-baud kernel) and once through the
+    Receiver-shaped afsk_demod_batch_uniform (one kernel per bit_frames).  A batch with several
+    baud rates is, in the second run, split into one uniform launch per rate and scattered back
+    into one result -- so every parity case below pins both kernel families.  (Host entries pick the
+    uniform kernel themselves when their bit_frames array holds one value.)"""
+    mode = request.param
+
+    def wrapped(samples, stream_offset, stream_len, bit_frames, amp_end_threshold=14000, out=None,
+                out_stride=None, stream=None, validate=True, diagnostics=False, margin_stride=None, entry="auto"):
+        import torch
+        n = int(stream_offset.numel())
+        kw = dict(stream=stream, diagnostics=diagnostics, margin_stride=margin_stride)
+        if mode == "mixed":
+            return REAL_DEMOD_BATCH(samples, stream_offset, stream_len, bit_frames, amp_end_threshold, out=out,
+                                    out_stride=out_stride, validate=validate, entry="mixed", **kw)
+        bf_h = (bit_frames.cpu().numpy() if isinstance(bit_frames, torch.Tensor)
+                else np.broadcast_to(np.asarray(bit_frames, np.int32), (n,)))
+        if validate and n:
+            batch.validate_bit_frames(bf_h)
+        values = sorted(set(int(v) for v in bf_h))
+        if len(values) <= 1:
+            return REAL_DEMOD_BATCH(samples, stream_offset, stream_len, values[0] if values else 40,
+                                    amp_end_threshold, out=out, out_stride=out_stride, validate=False,
+                                    entry="uniform", **kw)
+        if out is None:
+            out = batch.alloc_result(n, int(out_stride), samples.device)
+        stride = int(out.bytes.shape[1])
+        if diagnostics:
+            if out.corrected is None:
+                out.corrected = torch.zeros(n, dtype=torch.int32, device=samples.device)
+            if out.margins is None:
+                out.margins = torch.zeros((n, int(margin_stride)), dtype=torch.int32, device=samples.device)
+            kw["margin_stride"] = int(out.margins.shape[1])
+        for v in values:
+            idx = torch.from_numpy(np.nonzero(bf_h == v)[0]).to(samples.device)
+            part = REAL_DEMOD_BATCH(samples, stream_offset[idx].contiguous(), stream_len[idx].contiguous(), v,
+                                    amp_end_threshold, out_stride=stride, validate=False, entry="uniform", **kw)
+            for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status") + (("corrected", "margins") if diagnostics else ()):
+                getattr(out, f)[idx] = getattr(part, f)
+        return out
+
+    monkeypatch.setattr(batch, "demod_batch", wrapped)
+    return mode
+
+
 def assert_same(got, want, tag=""):
     """got: HostDemodResult, want: oracle dict."""
     for f in FIELDS:
@@ -702,18 +753,17 @@ def test_every_alignment_shift_and_short_tail_all_fast_bauds(torch_cuda):
     assert (got.nbytes > 100).any() and (got.nbits % 14 != 0).any()
 
 
-def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
-    """Launches of 8192+ streams arm the L2 warming requests behind the ring start (kWarmMinStreams,
-    afsk_demod_fast.h), which shifts the in-flight accounting of the first rounds on every
-    single-pass path: 8256 short streams cycling through all 16 single-pass baud rates (plus one
-    two-pass rate), ragged lengths around the 24 KiB the warming covers, odd leads, some noisy --
-    every output equals the CPU oracle's."""
-    torch = torch_cuda
-    rng = np.random.default_rng(99)
-    bauds_all = (300, 400, 480, 500, 600, 750, 800, 1000, 1200, 1500, 2000, 2400, 3000, 4000, 6000, 12000, 200)
-    n = 8256
+LARGE_LAUNCH_BAUDS = (300, 400, 480, 500, 600, 750, 800, 1000, 1200, 1500, 2000, 2400, 3000, 4000, 6000, 12000, 200)
+
+
+def large_launch_streams(n, bauds, seed):
+    """n short ragged streams cycling through `bauds`: lengths around the 24 KiB the L2 warming covers,
+    odd leads, some noisy, and streams that defeat the tail hint of large launches (sparse amplitude
+    probes decide how far to prefetch): a signal weaker than the squelch threshold (every probe
+    "quiet", yet the training phase decodes it), a late start behind silence, two bursts with a gap."""
+    rng = np.random.default_rng(seed)
     protos = {}
-    for baud in bauds_all:
+    for baud in bauds:
         t = afskmodem.Transmitter(baud, 0.08)
         ws = []
         for k in range(4):
@@ -722,17 +772,14 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
         protos[baud] = ws
     pieces, bfs = [], []
     for i in range(n):
-        baud = bauds_all[i % len(bauds_all)]
-        w = protos[baud][(i // len(bauds_all)) % 4]
+        baud = bauds[i % len(bauds)]
+        w = protos[baud][(i // len(bauds)) % 4]
         lead = int(rng.integers(0, 40)) if i % 3 else 0
         x = np.concatenate([np.zeros(lead, np.int16), w])
         L = int(rng.integers(11000, 15000)) if i % 5 else len(x)
         x = x[:L] if L <= len(x) else np.concatenate([x, np.zeros(L - len(x), np.int16)])
         if i % 7 == 0:
             x = np.clip(x.astype(np.int32) + rng.integers(-6000, 6000, len(x)), -32768, 32767).astype(np.int16)
-        # streams that defeat the tail hint of large launches (sparse amplitude probes decide how far
-        # to prefetch): a signal weaker than the squelch threshold (every probe "quiet", yet the
-        # training phase decodes it), a late start behind silence, two bursts with a silent gap
         if i % 11 == 3:
             x = (x.astype(np.int32) * 3 // 25).astype(np.int16)
         elif i % 11 == 5:
@@ -742,18 +789,43 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda):
         pieces.append(x); bfs.append(48000 // baud)
     ln = np.array([len(p) for p in pieces], np.int32)
     off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
-    bf = np.array(bfs, np.int32)
-    flat = np.concatenate(pieces)
+    return np.concatenate(pieces), off, ln, np.array(bfs, np.int32)
+
+
+@pytest.mark.parametrize("n", [6200, 8256])
+def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
+    """Launches of 6144+ streams run the kernels with the tail hint (kHintMinStreams), from 8192 on also
+    with the L2 warming requests behind the ring start (kWarmMinStreams, afsk_demod_fast.h); both shift
+    the in-flight accounting of the rounds on every path.  6200 streams = hint only (the round loops
+    switch to the dynamic wait_landed / fetch_through schedule without the warming requests in the
+    count), 8256 = hint + warming.  Mixed entry: ONE launch cycling through all 16 compile-time rates
+    plus a run-time-geometry rate; uniform entry: one launch of n streams PER RATE (every uniform
+    kernel's large-launch form).  Every output equals the CPU oracle's."""
+    import os
+    torch = torch_cuda
     stride = 64
-    got = device_demod(torch, flat, off, ln, bf, stride=stride)
-    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=16)
-    assert_same(got, want, "large launch")
-    assert (got.nbytes > 0).sum() > n // 3
-    # the same streams in a launch below the threshold give the same answers (warming is timing only)
-    sub = slice(0, 4096)
-    got2 = device_demod(torch, flat[: int(off[4096])], off[sub], ln[sub], bf[sub], stride=stride)
-    for f in FIELDS:
-        assert np.array_equal(getattr(got2, f), getattr(got, f)[sub]), f
+    threads = os.cpu_count() or 16
+    if entry == "mixed":
+        flat, off, ln, bf = large_launch_streams(n, LARGE_LAUNCH_BAUDS, 99)
+        got = device_demod(torch, flat, off, ln, bf, stride=stride)
+        want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=threads)
+        assert_same(got, want, "large launch")
+        assert (got.nbytes > 0).sum() > n // 3
+        # the same streams in a launch below the threshold give the same answers (hint / warming are timing only)
+        sub = slice(0, 4096)
+        got2 = device_demod(torch, flat[: int(off[4096])], off[sub], ln[sub], bf[sub], stride=stride)
+        for f in FIELDS:
+            assert np.array_equal(getattr(got2, f), getattr(got, f)[sub]), f
+        return
+    for baud in LARGE_LAUNCH_BAUDS + (150,):
+        flat, off, ln, bf = large_launch_streams(n, (baud,), 1000 + baud)
+        dev = "cuda:0"
+        res = REAL_DEMOD_BATCH(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ln).to(dev),
+                               48000 // baud, 14000, out_stride=stride, entry="uniform")
+        torch.cuda.synchronize()
+        want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=threads)
+        assert_same(res.cpu(), want, f"uniform large launch, {baud} baud")
+        assert (want["nbytes"] > 0).sum() > n // 4, baud
 
 
 def test_runtime_geometry_rates_vs_oracle(torch_cuda):
@@ -975,34 +1047,6 @@ def test_fuzz_noise_streams_every_rate(torch_cuda):
             assert_same(got, want, f"fuzz baud {baud} amp_end {amp_end}")
 
 
-def test_kernel_time_sanity(torch_cuda):
-    """Not a benchmark (bench.py is): a loose guard against gross regressions -- a geometry that
-    silently falls off the single-pass ring, register spills, a lost prefetch.  4096 x 1 s streams
-    per rate; bounds are ~1.6x what the r2 kernel needs on the slowest box seen (62-73 us for the
-    documented range, 80-112 us for the run-time geometry)."""
-    torch = torch_cuda
-    limits = {1200: 100.0, 300: 105.0, 2400: 105.0, 480: 110.0, 800: 110.0, 6000: 110.0, 12000: 120.0,
-              250: 160.0, 100: 150.0}
-    for baud, limit_us in limits.items():
-        b = synth_batch(torch, 4096, (baud,), seed=5, payload_len=synth.one_second_payload(baud),
-                        wav_quirk=baud != 12000)
-        stride = batch.out_stride_for(48000, 48000 // baud)
-        out = batch.alloc_result(4096, stride, "cuda:0")
-        for _ in range(30):
-            batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out=out, validate=False)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out=out, validate=False)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 50 * 1e3
-        assert us < limit_us, f"{baud} baud: {us:.1f} us per 4096 x 1 s launch (limit {limit_us})"
-        got = out.cpu()
-        assert (got.nbytes == synth.one_second_payload(baud)).all()
-
-
 def test_max_size_config5_on_one_gpu(torch_cuda):
     """BASELINE config #5's whole stream count (524288 x 1 s @1200 baud = 50 GB, normally
     sharded over 8 GPUs) on ONE MI355X: every stream decodes to its payload, and a
@@ -1025,12 +1069,15 @@ def test_max_size_config5_on_one_gpu(torch_cuda):
     torch.cuda.empty_cache()
 
 
-def test_launch_is_graph_capture_safe(torch_cuda):
+def test_launch_is_graph_capture_safe(torch_cuda, entry):
     """The C-ABI launch path does no allocation / synchronisation, so a sequence of demod
     launches can be captured into a HIP graph and replayed (guideline: no hipMalloc / sync in
-    the launch function)."""
+    the launch function).  Mixed entry: a three-rate batch with bit_frames on the device; uniform
+    entry: one rate, bit_frames by value."""
     torch = torch_cuda
-    b = synth_batch(torch, 256, (300, 1200, 2400), seed=99)
+    b = synth_batch(torch, 256, (300, 1200, 2400) if entry == "mixed" else (2400,), seed=99)
+    if entry == "uniform":
+        b["bf"] = 20
     stride = batch.out_stride_for(48000, 20)
     ref_out = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride).cpu()
     outs = [batch.alloc_result(256, stride, "cuda:0") for _ in range(3)]

@@ -227,6 +227,48 @@ def test_cabi_argument_checks_new_entries():
         assert lib.afsk_demod_streams_host(ptrs, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000,
                                            1, *outs) == _native.E_NO_DEVICE
     assert lib.afsk_host_scratch_release() == 0           # nothing cached: still fine
+    # the Receiver-shaped uniform entry validates its ONE bit_frames on the host, before any device call
+    u_tail = (None, 8, None, None, None, None, None, None, None, 0, None)
+    for bad_bf in (10, 0, 2, 2048, -40, 4098):
+        assert lib.afsk_demod_batch_uniform(None, None, None, bad_bf, 14000, 4, *u_tail) == _native.E_INVALID_BAUD
+    assert "bit_frames" in _native.last_error()
+    assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, -1, *u_tail) == _native.E_INVALID_ARG
+    assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 0, *u_tail) == 0
+    assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 4, *u_tail) == _native.E_INVALID_ARG   # null pointers
+
+
+def test_wav_probe_survives_fork(tmp_path):
+    """the file-ingest entries keep a persistent thread pool; after fork() the
+    child has the pool object but none of its threads.  afsk_wav_probe is host-only, so forked workers
+    (multiprocessing fork, DataLoader) are a plausible caller: the child must build its own pool
+    instead of waiting for workers that do not exist."""
+    import signal
+    names = []
+    for i in range(12):
+        fn = str(tmp_path / f"f{i}.wav")
+        afskmodem.Transmitter(1200, 0.02).save(bytes([65 + i]) * 3, fn)
+        names.append(fn)
+    want = [a.tolist() for a in batch.wav_probe(names)]          # parent: the pool now has workers
+    assert all(st == 0 for st in want[2])
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                                 # child
+        code = 1
+        try:
+            signal.alarm(20)                                     # a deadlock ends the child, not the suite
+            got = [a.tolist() for a in batch.wav_probe(names)]
+            got2 = [a.tolist() for a in batch.wav_probe(names[:5])]
+            code = 0 if (got == want and got2 == [v[:5] for v in want]) else 2
+            os.write(w, b"ok" if code == 0 else b"bad")
+        finally:
+            os._exit(code)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    msg = os.read(r, 16)
+    os.close(r)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"child status {status:#x} (SIGALRM = deadlock)"
+    assert msg == b"ok"
+    assert [a.tolist() for a in batch.wav_probe(names)] == want   # the parent's pool still works
 
 
 def build_cabi_smoke(tmp_path):

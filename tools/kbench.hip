@@ -12,51 +12,76 @@
 #include <vector>
 
 #include "../afskmodem_amd/csrc/afsk_demod_impl.h"
+#include "afsk_twopass.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 using afsk::DemodArgs;
 typedef void (*launch_fn)(const DemodArgs&, hipStream_t);
 
-template <int FLAGS, bool FAST>
-static void launch_flags(const DemodArgs& a, hipStream_t s) {
+static void launch_twopass(const DemodArgs& a, hipStream_t s) {
     const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
-    hipLaunchKernelGGL((afsk::demod_kernel_t<FLAGS, FAST>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
+    hipLaunchKernelGGL((afsk::demod_twopass_kernel_t<0>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
 }
 
-template <int WPB, int LDSW>
-static void launch_geom(const DemodArgs& a, hipStream_t s) {
-    const int blocks = (a.n_streams + WPB - 1) / WPB;
-    hipLaunchKernelGGL((afsk::demod_kernel_t<0, true, WPB, LDSW>), dim3(blocks), dim3(64 * WPB), 0, s, a);
+// the MIXED-baud kernel compiled into this tool (FLAGS = diagnostics); BIG as launch_demod picks it
+#ifdef KBENCH_MIXED
+template <int FLAGS>
+static void launch_flags(const DemodArgs& a, hipStream_t s) {
+    const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
+    if (a.n_streams >= afsk::kHintMinStreams)
+        hipLaunchKernelGGL((afsk::demod_kernel_t<FLAGS, afsk::kWavesPerBlock, 0, true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((afsk::demod_kernel_t<FLAGS, afsk::kWavesPerBlock, 0, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, a);
+}
+
+#endif
+
+// the UNIFORM kernel of KBENCH_BF (compile-time, default 40 = 1200 baud) with diagnostic FLAGS
+#ifndef KBENCH_BF
+#define KBENCH_BF 40
+#endif
+template <int FLAGS>
+static void launch_uflags(const DemodArgs& a, hipStream_t s) {
+    const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
+    DemodArgs b = a;
+    b.uniform_bit_frames = KBENCH_BF;
+    if (a.n_streams >= afsk::kHintMinStreams)
+        hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
+    else
+        hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
 }
 
 // same kernel over 4 rotating copies of the input (1.6 GB working set at 4096 streams): defeats
 // any reuse of the 256 MiB Infinity Cache between back-to-back launches
 static const int16_t* g_copies[4] = {nullptr, nullptr, nullptr, nullptr};
 static int g_rot = 0;
-#ifndef KBENCH_LITE
-static void launch_rotating(const DemodArgs& a, hipStream_t s) {
-    DemodArgs b = a;
-    b.samples = g_copies[(g_rot++) & 3];
-    launch_flags<0, true>(b, s);
-}
-#endif
 
-// the product library's entry point (same kernel, compiled in its own translation unit)
+// the product library's entry points (same kernels, compiled in their own translation units)
 typedef int (*lib_demod_fn)(const int16_t*, const int64_t*, const int32_t*, const int32_t*, int32_t, int32_t,
                             uint8_t*, int32_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, void*);
-static lib_demod_fn g_lib_demod = nullptr;
-static void launch_lib(const DemodArgs& a, hipStream_t s) {
-    g_lib_demod(a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
-                a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
-}
-// a second build of the library (KBENCH_LIB_B=<path>): A/B of two source revisions in one process
-// (a colon-separated list loads up to four builds: "lib B entry", "lib C entry", ...)
-static lib_demod_fn g_lib_x[4] = {nullptr, nullptr, nullptr, nullptr};
+typedef int (*lib_uniform_fn)(const int16_t*, const int64_t*, const int32_t*, int32_t, int32_t, int32_t,
+                              uint8_t*, int32_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
+                              int32_t, void*);
+static int g_bf = 40;
+// up to five builds of the library: index 0 = ../afskmodem_amd/csrc/libafsk_amd.so, 1.. = KBENCH_LIB_B=<a.so:b.so:...>
+static lib_demod_fn g_lib_m[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+static lib_uniform_fn g_lib_u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 template <int I>
-static void launch_lib_x(const DemodArgs& a, hipStream_t s) {
-    g_lib_x[I](a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
+static void launch_lib_m(const DemodArgs& a, hipStream_t s) {
+    g_lib_m[I](a.samples, a.stream_offset, a.stream_len, a.bit_frames, a.amp_end, a.n_streams, a.out_bytes,
                a.out_stride, a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, s);
+}
+template <int I>
+static void launch_lib_u(const DemodArgs& a, hipStream_t s) {
+    g_lib_u[I](a.samples, a.stream_offset, a.stream_len, g_bf, a.amp_end, a.n_streams, a.out_bytes, a.out_stride,
+               a.out_nbytes, a.out_nbits, a.out_clock_idx, a.out_term_frame, a.out_status, nullptr, nullptr, 0, s);
+}
+template <int I>
+static void launch_lib_u_rot(const DemodArgs& a, hipStream_t s) {
+    DemodArgs b = a;
+    b.samples = g_copies[(g_rot++) & 3];
+    launch_lib_u<I>(b, s);
 }
 
 struct Variant { const char* name; launch_fn fn; bool exact; };
@@ -116,31 +141,28 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ob, (size_t)n * stride)); CK(hipMalloc(&d_i32, (size_t)n * 5 * 4));
     DemodArgs a{d_x, d_off, d_len, d_bf, 14000, n, d_ob, stride, d_i32, d_i32 + n, d_i32 + 2 * n, d_i32 + 3 * n, d_i32 + 4 * n};
 
-    // -DKBENCH_LITE: only the two-pass kernel is compiled in (seconds instead of minutes); the
-    // single-pass kernel is timed through the library entries (libafsk_amd.so and KBENCH_LIB_B).
+    // Compiled into this tool: the two-pass baseline and the UNIFORM kernel of KBENCH_BF with its
+    // diagnostic variants (-DKBENCH_MIXED adds the mixed-baud kernel: +45 s of compile time).  The product
+    // kernels are timed through the library entries (libafsk_amd.so and up to four KBENCH_LIB_B builds).
+    g_bf = bfv;
     std::vector<Variant> vs = {
-        {"v1 two-pass", launch_flags<0, false>, true},
-#ifndef KBENCH_LITE
-        {"v2 fast (nt)", launch_flags<0, true>, true},
-        {"v2 skip_sync", launch_flags<1, true>, true},
-        {"v2 skip_valu", launch_flags<2, true>, false},
-        {"v2 skip_sync+valu", launch_flags<3, true>, false},
-#endif
-#ifdef KBENCH_FULL
-        {"v2 prefix-window sync", launch_flags<8, true>, true},
-        {"v2 fast default-policy", launch_flags<4, true>, true},
-        {"wpb1 lds20K (8/CU)", launch_geom<1, 20480>, true},
-        {"wpb2 lds18.5K (8/CU)", launch_geom<2, 18944>, true},
-        // (9 waves per CU no longer fit: a wave needs 18 KiB of LDS since the tail-hint probes)
-        {"wpb3 lds18.5K (6/CU)", launch_geom<3, 18944>, true},
-        {"wpb1 lds18.5K (8/CU)", launch_geom<1, 18944>, true},
+        {"v1 two-pass (r1 baseline)", launch_twopass, true},
+#ifdef KBENCH_MIXED
+        {"mixed kernel (in-tool)", launch_flags<0>, true},
 #endif
     };
 #ifndef KBENCH_LITE
+    if (bfv == KBENCH_BF) {
+        vs.push_back({"uniform kernel (in-tool)", launch_uflags<0>, true});
+        vs.push_back({"uniform skip_sync", launch_uflags<1>, true});
+        vs.push_back({"uniform skip_valu", launch_uflags<2>, false});
+        vs.push_back({"uniform skip_sync+valu", launch_uflags<3>, false});
+    }
+    if (bfv == KBENCH_BF)
     {   // timeline of one launch of the diagnostic (stamped) build
         unsigned long long* d_st; CK(hipMalloc(&d_st, (size_t)n * 32)); CK(hipMemset(d_st, 0, (size_t)n * 32));
         DemodArgs as = a; as.debug_stamps = d_st;
-        for (int rep = 0; rep < 3; rep++) { launch_flags<64, true>(as, 0); CK(hipDeviceSynchronize()); }
+        for (int rep = 0; rep < 3; rep++) { launch_uflags<64>(as, 0); CK(hipDeviceSynchronize()); }
         std::vector<unsigned long long> st((size_t)n * 4);
         CK(hipMemcpy(st.data(), d_st, (size_t)n * 32, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull; for (int s = 0; s < n; s++) t0 = std::min(t0, st[4 * s]);
@@ -176,33 +198,34 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(p, d_x, (size_t)n * L * 2, hipMemcpyDeviceToDevice));
             g_copies[c] = p;
         }
-#ifndef KBENCH_LITE
-        vs.insert(vs.begin() + 2, Variant{"v2 fast, 4 rotating inputs", launch_rotating, true});
-#endif
     }
-    if (void* h = dlopen("../afskmodem_amd/csrc/libafsk_amd.so", RTLD_NOW)) {
-        g_lib_demod = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
-        if (g_lib_demod) vs.insert(vs.begin() + 1, Variant{"libafsk_amd.so entry", launch_lib, true});
-    }
-    if (const char* pb = getenv("KBENCH_LIB_B")) {
-        static const launch_fn tramp[4] = {launch_lib_x<0>, launch_lib_x<1>, launch_lib_x<2>, launch_lib_x<3>};
-        static std::string names[4];
-        std::string list(pb);
+    {
+        static const launch_fn tramp_m[5] = {launch_lib_m<0>, launch_lib_m<1>, launch_lib_m<2>, launch_lib_m<3>, launch_lib_m<4>};
+        static const launch_fn tramp_u[5] = {launch_lib_u<0>, launch_lib_u<1>, launch_lib_u<2>, launch_lib_u<3>, launch_lib_u<4>};
+        static std::string names_m[5], names_u[5];
+        std::string list = "../afskmodem_amd/csrc/libafsk_amd.so";
+        if (const char* pb = getenv("KBENCH_LIB_B")) list += std::string(":") + pb;
+        const bool skip_mixed = getenv("KBENCH_NO_MIXED") != nullptr;
         size_t pos = 0;
-        for (int i = 0; i < 4 && pos <= list.size(); i++) {
+        for (int i = 0; i < 5 && pos <= list.size(); i++) {
             size_t e = list.find(':', pos);
             std::string one = list.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
             pos = e == std::string::npos ? list.size() + 1 : e + 1;
             if (one.empty()) continue;
             if (void* h = dlopen(one.c_str(), RTLD_NOW | RTLD_LOCAL)) {
-                g_lib_x[i] = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
+                g_lib_m[i] = (lib_demod_fn)dlsym(h, "afsk_demod_batch");
+                g_lib_u[i] = (lib_uniform_fn)dlsym(h, "afsk_demod_batch_uniform");
                 size_t sl = one.rfind('/');
-                names[i] = std::string("lib ") + (char)('B' + i) + " " + (sl == std::string::npos ? one : one.substr(sl + 1));
-                if (g_lib_x[i]) vs.insert(vs.begin() + 2 + i, Variant{names[i].c_str(), tramp[i], true});
+                const std::string base = std::string("lib ") + (char)('A' + i) + " " + (sl == std::string::npos ? one : one.substr(sl + 1));
+                names_m[i] = base + " mixed";
+                names_u[i] = base + " uniform";
+                if (g_lib_m[i] && !skip_mixed) vs.push_back(Variant{names_m[i].c_str(), tramp_m[i], true});
+                if (g_lib_u[i]) vs.push_back(Variant{names_u[i].c_str(), tramp_u[i], true});
             } else {
                 printf("cannot load %s: %s\n", one.c_str(), dlerror());
             }
         }
+        if (g_lib_u[0] && g_copies[1]) vs.push_back(Variant{"lib A uniform, 4 rotating inputs", launch_lib_u_rot<0>, true});
     }
     if (const char* only = getenv("KBENCH_ONLY")) {          // run a single variant (cache-state studies)
         std::vector<Variant> keep;
