@@ -1,6 +1,8 @@
 // afsk_demod_fast.h -- stream-aligned single-pass path.  Included by afsk_demod_impl.h.
 // Covers every bit_frames value of the reference's documented 300 - 12000 baud range:
 //   20 / 40 / 80 / 160   (2400 / 1200 / 600 / 300 baud)        fast_rounds: 5 KiB rounds, 80-byte lane pieces
+//   240 / 320 / 480      (200 / 150 / 100 baud: below the documented range, but on the list of rates the
+//                         reference's code round-trips)         wm_rounds with 4 / 8 lanes per symbol
 //   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks, several
 //                                                              symbols per lane
 //   60 / 96 / 100 / 120  (800 / 500 / 480 / 400 baud)          wm_rounds: rounds of any size, watermark refill
@@ -311,27 +313,31 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
                                                               unsigned long long* stamps = nullptr) {
     constexpr int N = 2 * BF, Q = BF / 4, H = BF / 2, NOFF = kSync - N;
     constexpr int GC = 24, STEP = 64 * GC, T = (NOFF + STEP - 1) / STEP;
-    static_assert(Q % 8 == 0, "lags must be multiples of 8 samples (16-byte reads)");
-    static_assert(N % 8 == 0 && N / 8 <= 64, "offset 0 is correlated 8 samples per lane");
+    static_assert(Q % 4 == 0, "lags must be multiples of 4 samples (8-byte aligned sub-windows)");
     static_assert(2 * (STEP * (T - 1) + GC * 63 + N + GC) <= kRingBytes, "sub-windows outside the ring");
     constexpr uint32_t C = 65535u * (uint32_t)BF;
     constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
-    static_assert(N <= 512 && (1ull << 36) / N < (1ull << 32), "magic divisor out of range");
+    static_assert(N <= 1024 && (1ull << 36) / N < (1ull << 32) && 65535ull * N * N < (1ull << 36), "magic divisor out of range");
     const int lane = fr.lane;
     using std::integral_constant;
 
     fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
-    // total(0) = C + sum_j sigma_j x[j]: lane l < N/8 takes samples 8l .. 8l+7 (one sign)
+    // total(0) = C + sum_j sigma_j x[j] over the 2*BF template samples: dword m = samples 2m, 2m + 1 (Q is
+    // even, so both share one sign), lanes stride through the BF dwords
     uint32_t base;
     {
-        const int j0 = 8 * (lane < N / 8 ? lane : 0);
-        const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + 2 * j0);
         int32_t a = 0;
-        a = dot2_i16(t4[0], 0x00010001u, a); a = dot2_i16(t4[1], 0x00010001u, a);
-        a = dot2_i16(t4[2], 0x00010001u, a); a = dot2_i16(t4[3], 0x00010001u, a);
-        const bool hi = j0 < BF ? (((j0 / Q) & 1) == 0) : ((j0 - BF) < H);     // template is 32767 here
-        a = lane < N / 8 ? (hi ? -a : a) : 0;
+#pragma unroll
+        for (int it = 0; it < (BF + 63) / 64; it++) {
+            const int m = lane + 64 * it;
+            const int mc = m < BF ? m : 0;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(fr.ring + 4 * mc);
+            const int j0 = 2 * mc;
+            const bool hi = j0 < BF ? (((j0 / Q) & 1) == 0) : ((j0 - BF) < H);     // template is 32767 here
+            const int32_t v = dot2_i16(w, 0x00010001u, 0);
+            a += m < BF ? (hi ? -v : v) : 0;
+        }
         const int32_t sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(a), 63);
         base = C + (uint32_t)sum;
     }
@@ -347,8 +353,15 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
         for (int e = 0; e < 7; e++) {
 #pragma unroll
             for (int j = 0; j < GC / 8; j++) {
-                const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 2 * lag[e] + 16 * j);
-                R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
+                if constexpr (Q % 8 == 0) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 2 * lag[e] + 16 * j);
+                    R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
+                } else {          // lags are multiples of 8 bytes only (bit_frames 240: Q = 60)
+                    typedef u32x2 u32x2_al8 __attribute__((aligned(8)));
+                    const u32x2 ta = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j);
+                    const u32x2 tb = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j + 8);
+                    R[e][4 * j] = ta[0]; R[e][4 * j + 1] = ta[1]; R[e][4 * j + 2] = tb[0]; R[e][4 * j + 3] = tb[1];
+                }
             }
         }
         // run[k] = total(first + k + 1) - total(first)
@@ -621,13 +634,17 @@ __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, u
     }
 }
 
-// Sum of a value over the 2 or 4 lanes of a quad-aligned group, result in every lane (DPP).
+// Sum of a value over the 2, 4, 8 or 16 lanes of an aligned group, result in every lane of it (DPP only).
 template <int LPS>
 __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
-    static_assert(LPS == 2 || LPS == 4, "two or four lanes per symbol");
+    static_assert(LPS == 2 || LPS == 4 || LPS == 8 || LPS == 16, "2, 4, 8 or 16 lanes per symbol");
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
-    if constexpr (LPS == 4)
+    if constexpr (LPS >= 4)
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    if constexpr (LPS >= 8)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    if constexpr (LPS >= 16)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
     return v;
 }
 
@@ -1027,8 +1044,11 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 //              120: two lanes per symbol, 120-byte pieces (8-byte aligned), quarter sums
 template <int BF>
 struct WmGeom {
-    static constexpr bool valid = BF == 60 || BF == 96 || BF == 100 || BF == 120;
-    static constexpr int LPS = BF >= 96 ? 2 : 1;                  // lanes per symbol
+    static constexpr bool valid = BF == 60 || BF == 96 || BF == 100 || BF == 120 || BF == 240 || BF == 320 || BF == 480;
+    // lanes per symbol: a whole symbol (60), half a symbol (96 / 100 / 120), and for the long symbols of
+    // 200 / 150 / 100 baud a piece that lies inside ONE quarter of the symbol (both templates constant
+    // over it): 240 -> 4 x 60 samples, 320 -> 8 x 40, 480 -> 8 x 60
+    static constexpr int LPS = BF >= 320 ? 8 : (BF >= 240 ? 4 : (BF >= 96 ? 2 : 1));
     static constexpr int PL = BF / LPS;                           // samples per lane piece
     static constexpr int PB = 2 * PL;                             // bytes per piece
     static constexpr int NO = PL / 2;                             // dwords per piece
@@ -1036,7 +1056,8 @@ struct WmGeom {
     static constexpr int SPP = 64 / LPS;                          // symbols per round = per rxd pass
     static constexpr int RBYTES = 64 * PB;                        // bytes per round
     static_assert(!valid || (BF % 4 == 0 && PL % 2 == 0 && PB + 16 <= kMirrorBytes &&
-                             RBYTES + 16 + 1023 < kRingBytes && (LPS == 1 || (BF / 2) % 2 == 0)),
+                             RBYTES + 16 + 1023 < kRingBytes && (LPS == 1 || (BF / 2) % 2 == 0) &&
+                             (LPS < 4 || (BF / 4) % PL == 0)),
                   "round geometry");
 };
 
@@ -1113,6 +1134,15 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
                 mark = __builtin_amdgcn_sad_u16(lim, tm, mark);                          // ref:346
                 space = __builtin_amdgcn_sad_u16(lim, ts, space);                        // ref:347
             }
+        } else if constexpr (LPS >= 4) {
+            // the piece lies inside quarter `part / (LPS / 4)` of the symbol: mark template hi,lo,hi,lo over
+            // the quarters (ref:80-85), space template hi,hi,lo,lo (ref:68-77), both constant over the piece
+            uint32_t h = 0;
+#pragma unroll
+            for (int d = 0; d < NO; d++) h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, h);
+            const int quarter = part / (LPS / 4);
+            mark = (quarter & 1) ? FULL * PL - h : h;
+            space = quarter < 2 ? h : FULL * PL - h;
         } else if constexpr (Q % 2 == 0) {
             // half a symbol in the lane = quarters (hi, lo) of the mark tone (ref:80-85), all hi (part 0)
             // or all lo (part 1) of the space tone (ref:68-77); SAD against lo = 65535 * n - SAD against hi
@@ -1137,23 +1167,23 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
             mark = mk;
             space = part == 0 ? th : FULL * PL - th;
         }
-        if constexpr (LPS == 2) {
-            mark = quad_sum<2>(mark);
-            space = quad_sum<2>(space);
+        if constexpr (LPS >= 2) {
+            mark = quad_sum<LPS>(mark);
+            space = quad_sum<LPS>(space);
         }
         const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
         const bool bit = md < sd;                                                        // ref:348-351
         if (margins && part == 0 && k0 + lane / LPS < mlim) margins[k0 + lane / LPS] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < SPP ? (K - k0) : SPP;
         uint64_t bmask = __ballot(bit);
-        if constexpr (LPS == 2) bmask = compress_bits<2>(bmask);
+        if constexpr (LPS >= 2) bmask = compress_bits<LPS>(bmask);
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
             uint32_t amp = 0;
 #pragma unroll
             for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);   // ref:94-98
-            if constexpr (LPS == 2) amp = quad_sum<2>(amp);
+            if constexpr (LPS >= 2) amp = quad_sum<LPS>(amp);
             uint64_t am = __ballot(amp >= amp_thr);
-            if constexpr (LPS == 2) am = compress_bits<2>(am);
+            if constexpr (LPS >= 2) am = compress_bits<LPS>(am);
             return am;
         });
         if (rd.st.phase == 2) break;
@@ -1483,7 +1513,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     } else {
         // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
         // not: 72 + 320 samples), sub-windows in steps otherwise
-        constexpr bool LANES_FORM = BF <= 120;
+        constexpr bool LANES_FORM = BF <= 120;         // 160 / 240 / 320 / 480: sub-windows in steps
         if constexpr (LANES_FORM)
             ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else

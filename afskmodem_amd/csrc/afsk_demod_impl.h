@@ -192,7 +192,7 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 // (FLAGS & 64: per-wave s_memrealtime stamps into DemodArgs::debug_stamps)
 
 // every bit_frames with a compile-time geometry (everything else: the run-time geometry)
-#define AFSK_FAST_BF_LIST(X) X(4) X(8) X(12) X(16) X(20) X(24) X(32) X(40) X(48) X(60) X(64) X(80) X(96) X(100) X(120) X(160)
+#define AFSK_FAST_BF_LIST(X) X(4) X(8) X(12) X(16) X(20) X(24) X(32) X(40) X(48) X(60) X(64) X(80) X(96) X(100) X(120) X(160) X(240) X(320) X(480)
 
 __host__ __device__ constexpr bool bit_frames_valid(int bf) {       // ref:68-85, 327: templates exist, sync window fits
     return bf >= 4 && (bf & 3) == 0 && 2 * bf < kSync;

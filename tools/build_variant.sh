@@ -14,3 +14,12 @@ for e in "$@"; do sed -i "$e" "$W"/afskmodem_amd/csrc/*.h "$W"/afskmodem_amd/csr
 (cd "$W/afskmodem_amd/csrc" && bash build.sh >/dev/null)
 cp "$W/afskmodem_amd/csrc/libafsk_amd.so" "$ROOT/tools/libafsk_$name.so"
 echo "built tools/libafsk_$name.so"
+# KBENCH=1: also build tools/kbench_<name> against the patched sources (its in-tool kernels -- timeline
+# stamps, skip_sync / skip_valu ablations -- then come from the variant too)
+if [ "${KBENCH:-0}" = "1" ]; then
+  mkdir -p "$W/tools"
+  cp "$ROOT/tools/kbench.hip" "$ROOT/tools/afsk_twopass.h" "$W/tools/"
+  (cd "$W/tools" && hipcc -O3 -std=c++17 --offload-arch=${AFSK_ARCH:-gfx950} -Wno-unused-function ${KBENCH_DEFS:-} -o "$ROOT/tools/kbench_$name" kbench.hip \
+      ../afskmodem_amd/csrc/afsk_synth.hip ../afskmodem_amd/csrc/afsk_gate.hip -ldl)
+  echo "built tools/kbench_$name"
+fi

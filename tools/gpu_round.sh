@@ -1,26 +1,29 @@
 #!/bin/bash
-# One GPU visit: parity tests, smoke, the bench line (N = 1: config2 + sub-records config3/4/5),
-# and with "prof" rocprofv3 kernel trace + PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-# runs) for config2, config3 and two custom baud rates.  Outputs under gpurun_out/.
+# One GPU visit: parity tests, smoke, the bench line (N = 1: config5 headline + sub-records config2/3/4
+# + f1/f2/f3), and with "prof" rocprofv3 kernel trace + PMC passes (FETCH_SIZE and WRITE_SIZE in
+# separate runs) for the workloads listed in PROF_WL.  Outputs under gpurun_out/.
 #   bash tools/gpu_round.sh [prof] [tag]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export PROF_TAG=${2:-r2}
-( timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/pytest_gpu.log
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) | tee gpurun_out/smoke.log
-( timeout 900 python bench.py --steps 200 --warmup 20 2>&1 | grep '^{"metric"' ) | tee gpurun_out/bench_main.json
+export PROF_TAG=${2:-r3}
+T=$PROF_TAG
+( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/${T}_pytest_gpu.log
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) | tee gpurun_out/${T}_smoke.log
+( timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/${T}_bench_main.err | grep '^{"metric"' ) > gpurun_out/${T}_bench_main.json
+cut -c1-600 gpurun_out/${T}_bench_main.json
 if [ "${1:-}" = "prof" ]; then
   R=$(pwd)
-  for w in config2 config3 custom480 custom12000; do
-    steps=200; wl="--workload $w"
-    [ $w = config3 ] && steps=20
-    [ $w = custom480 ] && wl="--workload custom --bauds 480"
-    [ $w = custom12000 ] && wl="--workload custom --bauds 12000"
+  for w in ${PROF_WL:-config5 config2 config3}; do
+    steps=200; wl="--workload $w"; kern=demod
+    case $w in
+      config5|config3|config4) steps=20 ;;
+      custom*) wl="--workload custom --bauds ${w#custom}" ;;
+    esac
     rm -rf gpurun_out/prof_trace_$w gpurun_out/prof_pmc1_$w gpurun_out/prof_pmc2_$w
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace_$w -- python3 $R/bench.py $wl --sub "" --steps $steps --warmup 3 --no-cpu-baseline 2>&1 | grep '^{"metric"' | tee $R/gpurun_out/prof_bench_$w.json | cut -c1-300 )
-    ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_pmc1_$w -- python3 $R/bench.py $wl --sub "" --steps 6 --warmup 2 --preroll-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
-    ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_pmc2_$w -- python3 $R/bench.py $wl --sub "" --steps 6 --warmup 2 --preroll-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
+    ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_pmc1_$w -- python3 $R/bench.py $wl --sub "" --steps 6 --warmup 2 --preroll-ms 0 --min-region-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
+    ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_pmc2_$w -- python3 $R/bench.py $wl --sub "" --steps 6 --warmup 2 --preroll-ms 0 --min-region-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-100 )
     python tools/summarize_prof.py gpurun_out $w $steps 2>&1 | tail -40
     python tools/trace_timeline.py gpurun_out/prof_trace_$w 2>&1 | tee gpurun_out/timeline_$w.txt
   done
