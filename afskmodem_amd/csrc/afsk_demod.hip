@@ -12,6 +12,7 @@ hipError_t launch_demod_small(const DemodArgs& a, int blocks, hipStream_t stream
 hipError_t launch_demod_big(const DemodArgs& a, int blocks, hipStream_t stream);
 #define AFSK_X(B) hipError_t launch_demod_uniform_##B(const DemodArgs& a, int blocks, bool big, hipStream_t stream);
 AFSK_FAST_BF_LIST(AFSK_X)
+AFSK_GP_BF_LIST(AFSK_X)
 AFSK_X(0)
 #undef AFSK_X
 
@@ -31,6 +32,7 @@ hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream) {
     switch (a.uniform_bit_frames) {
 #define AFSK_X(B) case B: return launch_demod_uniform_##B(a, blocks, big, stream);
         AFSK_FAST_BF_LIST(AFSK_X)
+        AFSK_GP_BF_LIST(AFSK_X)
 #undef AFSK_X
         default: return launch_demod_uniform_0(a, blocks, big, stream);       // run-time geometry
     }

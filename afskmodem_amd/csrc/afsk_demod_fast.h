@@ -313,18 +313,21 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
                                                               unsigned long long* stamps = nullptr) {
     constexpr int N = 2 * BF, Q = BF / 4, H = BF / 2, NOFF = kSync - N;
     constexpr int GC = 24, STEP = 64 * GC, T = (NOFF + STEP - 1) / STEP;
-    static_assert(Q % 4 == 0, "lags must be multiples of 4 samples (8-byte aligned sub-windows)");
     static_assert(2 * (STEP * (T - 1) + GC * 63 + N + GC) <= kRingBytes, "sub-windows outside the ring");
     constexpr uint32_t C = 65535u * (uint32_t)BF;
-    constexpr uint32_t M = (uint32_t)(((1ull << 36) + N - 1) / N);
-    static_assert(N <= 1024 && (1ull << 36) / N < (1ull << 32) && 65535ull * N * N < (1ull << 36), "magic divisor out of range");
+    // floor(m / N) = mul_hi(m, ceil(2^36 / N)) >> 4 while m * N < 2^36 (m <= 65535 * N: N <= 960);
+    // longer templates use the float estimate + fix-up of div_exact (quotient < 2^16)
+    constexpr bool MAGIC = 65535ull * N * N < (1ull << 36);
+    constexpr uint32_t M = MAGIC ? (uint32_t)(((1ull << 36) + N - 1) / N) : 0u;
+    static_assert((1ull << 36) / N < (1ull << 32), "magic divisor out of range");
     const int lane = fr.lane;
     using std::integral_constant;
 
     fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
-    // total(0) = C + sum_j sigma_j x[j] over the 2*BF template samples: dword m = samples 2m, 2m + 1 (Q is
-    // even, so both share one sign), lanes stride through the BF dwords
+    // total(0) = C + sum_j sigma_j x[j] over the 2*BF template samples: dword m = samples 2m, 2m + 1,
+    // lanes stride through the BF dwords; sigma = -1 where the template is 32767 (per sample: with an odd
+    // quarter length a dword straddles a sign change)
     uint32_t base;
     {
         int32_t a = 0;
@@ -333,10 +336,15 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
             const int m = lane + 64 * it;
             const int mc = m < BF ? m : 0;
             const uint32_t w = *reinterpret_cast<const uint32_t*>(fr.ring + 4 * mc);
-            const int j0 = 2 * mc;
-            const bool hi = j0 < BF ? (((j0 / Q) & 1) == 0) : ((j0 - BF) < H);     // template is 32767 here
-            const int32_t v = dot2_i16(w, 0x00010001u, 0);
-            a += m < BF ? (hi ? -v : v) : 0;
+            uint32_t cf = 0;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int j = 2 * mc + half;
+                const bool hi = j < BF ? (((j / Q) & 1) == 0) : ((j - BF) < H);
+                cf |= (hi ? 0xFFFFu : 0x0001u) << (16 * half);
+            }
+            const int32_t v = dot2_i16(w, cf, 0);
+            a += m < BF ? v : 0;
         }
         const int32_t sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(a), 63);
         base = C + (uint32_t)sum;
@@ -356,11 +364,15 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
                 if constexpr (Q % 8 == 0) {
                     const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 2 * lag[e] + 16 * j);
                     R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
-                } else {          // lags are multiples of 8 bytes only (bit_frames 240: Q = 60)
+                } else if constexpr (Q % 4 == 0) {   // lags are multiples of 8 bytes only (bit_frames 240: Q = 60)
                     typedef u32x2 u32x2_al8 __attribute__((aligned(8)));
                     const u32x2 ta = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j);
                     const u32x2 tb = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j + 8);
                     R[e][4 * j] = ta[0]; R[e][4 * j + 1] = ta[1]; R[e][4 * j + 2] = tb[0]; R[e][4 * j + 3] = tb[1];
+                } else {                              // any quarter length: 2-byte aligned sub-windows (gfx950 reads them)
+                    typedef u32x4 u32x4_al2 __attribute__((aligned(2)));
+                    const u32x4 t4 = *reinterpret_cast<const u32x4_al2*>(src + 2 * lag[e] + 16 * j);
+                    R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
                 }
             }
         }
@@ -390,7 +402,8 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
         }
     });
     const uint32_t m = __builtin_amdgcn_readfirstlane(wave_min_u32(min_total));
-    const uint32_t bound = ((__umulhi(m, M) >> 4) + 1u) * (uint32_t)N;     // (min mean + 1) * N
+    const uint32_t mean = MAGIC ? (__umulhi(m, M) >> 4) : div_exact(m, (uint32_t)N, 1.0f / (float)N);
+    const uint32_t bound = (mean + 1u) * (uint32_t)N;                      // (min mean + 1) * N
     uint32_t cand = 0xFFFFFFFFu;
     static_for<0, T * GC>([&](auto kc) {
         constexpr int k = T * GC - 1 - decltype(kc)::value;                // last to first: first wins
@@ -1190,6 +1203,153 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     }
 }
 
+// ---- general pieces: any bit_frames as a COMPILE-TIME value (uniform kernels) ------------------------
+// The remaining rates a Receiver can be built for (48000 / baud a divisor of 48000 and a multiple of 4:
+// bit_frames 128, 192, 200, 300, 384, 400, 500, 600, 640, 800, 960, 1000, 1200, 1500, 1600, 1920, 2000
+// = 375 ... 24 baud) have symbols that neither tile a round of chunks nor split into 2^k equal pieces of
+// whole dwords inside one quarter (quarter lengths like 75 or 125 samples).  Here a symbol is split over
+// LPS = 4 ... 64 lanes at DWORD granularity: quarter k of the symbol (template constant over it: mark
+// hi,lo,hi,lo ref:80-85, space hi,hi,lo,lo ref:68-77) owns the dwords whose first sample lies in it, and
+// its LPS/4 lanes share them as evenly as whole dwords allow -- every lane gets NB + 1 or NB + 2
+// consecutive dwords.  Only the LAST dword of a lane can straddle into the next quarter (odd quarter
+// length), so a lane runs NB dwords against its constant template (ONE v_sad_u16 against "hi" per dword
+// serves both correlators: SAD against lo = 65535 * n - SAD against hi) and two tail slots with per-lane
+// template dwords (the second one masked off for lanes with NB + 1 dwords).  All 64 lanes work for every
+// bit_frames; rounds are 3.8 - 7.5 KiB of whole symbols with the watermark refill, linear reads into the
+// mirror behind the ring, 2-byte-aligned dword reads (a clock index may be odd).
+template <int BF>
+struct GpGeom {
+    static constexpr int Q = BF / 4, D = BF / 2;
+    static constexpr int pick_lps() {
+        int l = 4;
+        while (l < 64 && (64 / l) * 2 * BF > 7680) l *= 2;
+        return l;
+    }
+    static constexpr int LPS = pick_lps();                        // lanes per symbol
+    static constexpr int LPQ = LPS / 4;                           // lanes per quarter symbol
+    static constexpr int SPP = 64 / LPS;                          // symbols per round = per rxd pass
+    static constexpr int RBYTES = SPP * 2 * BF;                   // bytes per round
+    static constexpr int qs(int k) { return (k * Q + 1) / 2; }    // first dword owned by quarter k
+    static constexpr int piece(int k, int j) {                    // dwords of lane j of quarter k
+        return ((j + 1) * (qs(k + 1) - qs(k))) / LPQ - (j * (qs(k + 1) - qs(k))) / LPQ;
+    }
+    static constexpr int min_piece() {
+        int m = 1 << 30;
+        for (int k = 0; k < 4; k++) for (int j = 0; j < LPQ; j++) m = piece(k, j) < m ? piece(k, j) : m;
+        return m;
+    }
+    static constexpr int max_piece() {
+        int m = 0;
+        for (int k = 0; k < 4; k++) for (int j = 0; j < LPQ; j++) m = piece(k, j) > m ? piece(k, j) : m;
+        return m;
+    }
+    static constexpr int NB = min_piece() - 1;                    // dwords every lane runs against its constant template
+    static constexpr bool valid = BF % 4 == 0 && BF >= 64 && 2 * BF < kSync && NB >= 1 && max_piece() <= NB + 2 &&
+                                  4 * (NB + 2) + 4 <= kMirrorBytes && RBYTES + 4 + 1023 < kRingBytes;
+};
+
+// sum over the LPS lanes of an aligned group; the result is valid in the LAST lane of the group (for LPS
+// <= 16 in every lane: DPP inside a row; 32 / 64 lanes add the row totals with row_bcast:15 / :31)
+template <int LPS>
+__device__ __forceinline__ uint32_t group_sum_last(uint32_t v) {
+    if constexpr (LPS <= 16) {
+        return quad_sum<LPS>(v);
+    } else {
+        v = quad_sum<16>(v);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 -> rows 1, 3
+        if constexpr (LPS == 64)
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+        return v;
+    }
+}
+
+// bit (g * LPS + LPS - 1) of a wave-uniform mask -> bit g (the last lane of every group)
+template <int LPS>
+__device__ __forceinline__ uint64_t compress_bits_last(uint64_t x) {
+    if constexpr (LPS == 64) return x >> 63;
+    else if constexpr (LPS == 32) return ((x >> 31) & 1ull) | ((x >> 62) & 2ull);
+    else return compress_bits<LPS>(x >> (LPS - 1));
+}
+
+template <int BF, int FLAGS, bool HINTED>
+__device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
+                                          uint32_t amp_thr, RxDeferred& rd,
+                                          unsigned long long* words, uint8_t* out_row,
+                                          int out_stride, int32_t* margins, int32_t mstride) {
+    using G = GpGeom<BF>;
+    static_assert(G::valid, "no general-piece geometry for this bit_frames");
+    constexpr int Q = G::Q, LPS = G::LPS, LPQ = G::LPQ, SPP = G::SPP, RBYTES = G::RBYTES, NB = G::NB;
+    constexpr uint32_t FULL = 65535u;
+    const int lane = fr.lane;
+    const int part = lane & (LPS - 1), sym = lane / LPS;
+    const int32_t mlim = K < mstride ? K : mstride;
+    // this lane's piece of every symbol it works on: dwords [d0, d0 + n) of quarter k
+    const int k = part / LPQ, j = part % LPQ;
+    const int q0 = (k * Q + 1) >> 1, q1 = ((k + 1) * Q + 1) >> 1;
+    const int d0 = q0 + (j * (q1 - q0)) / LPQ, d1 = q0 + ((j + 1) * (q1 - q0)) / LPQ;
+    const bool two = (d1 - d0) == NB + 2;                         // NB + 2 dwords (else NB + 1)
+    const bool mark_hi = (k & 1) == 0, space_hi = k < 2;          // quarter k: mark hi,lo,hi,lo / space hi,hi,lo,lo
+    const uint32_t cm = mark_hi ? 0xFFFFFFFFu : 0u, cs = space_hi ? 0xFFFFFFFFu : 0u;
+    // the last dword of the piece: its second sample may already belong to the next quarter
+    const int kl = (2 * d1 - 1) / Q;
+    const uint32_t lm = (cm & 0xFFFFu) | (((kl & 1) == 0 ? 0xFFFFu : 0u) << 16);
+    const uint32_t ls = (cs & 0xFFFFu) | ((kl < 2 ? 0xFFFFu : 0u) << 16);
+    const uint32_t tmA = two ? cm : lm, tsA = two ? cs : ls;      // tail slot A = dword NB of the piece
+    const int piece_byte = sym * 2 * BF + 4 * d0;
+    int pos = byte0;                                              // stream byte of the round's first sample
+    for (int r = 0; r < NR; r++, pos += RBYTES) {
+        const int last = pos + RBYTES + 3;                        // tail slot B of the last lane reaches one dword further
+        if constexpr (HINTED) fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+        fr.wait_landed(last >> 10);
+        if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0, 4);
+        const int rb = pos & (kRingBytes - 1);
+        if (rb + RBYTES + 4 > kRingBytes) {                       // a piece runs past the ring end: refresh the mirror
+            if (lane < kMirrorBytes / 16)
+                *reinterpret_cast<u32x4*>(fr.ring + kRingBytes + 16 * lane) =
+                    *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
+            wave_lds_sync();
+        }
+        const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));
+        typedef uint32_t u32_al2 __attribute__((aligned(2)));
+        uint32_t x[NB + 2];
+#pragma unroll
+        for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const u32_al2*>(src + 4 * d);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
+        fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
+
+        uint32_t h = 0, amp = 0;
+#pragma unroll
+        for (int d = 0; d < NB; d++) {
+            h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, h);         // ref:344, 346-347
+            amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);                      // ref:94-98
+        }
+        const uint32_t la = limit_pair_biased(x[NB]), lb = limit_pair_biased(x[NB + 1]);
+        uint32_t mark = mark_hi ? h : FULL * (2u * NB) - h;
+        uint32_t space = space_hi ? h : FULL * (2u * NB) - h;
+        mark = __builtin_amdgcn_sad_u16(la, tmA, mark);
+        space = __builtin_amdgcn_sad_u16(la, tsA, space);
+        amp = __builtin_amdgcn_sad_u16(x[NB] ^ kBias, kBias, amp);
+        const uint32_t mb = __builtin_amdgcn_sad_u16(lb, lm, 0u), sb = __builtin_amdgcn_sad_u16(lb, ls, 0u);
+        const uint32_t ab = __builtin_amdgcn_sad_u16(x[NB + 1] ^ kBias, kBias, 0u);
+        mark += two ? mb : 0u;
+        space += two ? sb : 0u;
+        amp += two ? ab : 0u;
+        mark = group_sum_last<LPS>(mark);
+        space = group_sum_last<LPS>(space);
+        const int k0 = r * SPP;
+        const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+        const bool bit = md < sd;                                                        // ref:348-351
+        if (margins && part == LPS - 1 && k0 + sym < mlim) margins[k0 + sym] = (int32_t)sd - (int32_t)md;
+        const int nv = (K - k0) < SPP ? (K - k0) : SPP;
+        const uint64_t bmask = compress_bits_last<LPS>(__ballot(bit));
+        rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
+            const uint32_t asum = group_sum_last<LPS>(amp);
+            return compress_bits_last<LPS>(__ballot(asum >= amp_thr));
+        });
+        if (rd.st.phase == 2) break;
+    }
+}
+
 // ---- every other valid bit_frames (a RUNTIME value) on the single-pass ring -------------------
 // Every valid bit_frames without a compile-time geometry: 28, 36, 44 ... 124 and everything from 128 up
 // (375 baud and below: outside the reference's documented range, but its code decodes them).  Same ring, watermark refill and mirror as wm_rounds; the symbol geometry is
@@ -1489,7 +1649,8 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     const bool warm = BIG && warm_arg, hint = BIG && hint_arg;
     constexpr bool MULTI = MultiGeom<BF>::valid;
     constexpr bool WM = WmGeom<BF>::valid;
-    constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : 2560 / BF);   // symbols per round
+    constexpr bool GP = !MULTI && !WM && BF != 20 && BF != 40 && BF != 80 && BF != 160;   // general pieces
+    constexpr int SPR = MULTI ? MultiGeom<BF>::SPR : (WM ? WmGeom<BF>::SPP : (GP ? GpGeom<GP ? BF : 128>::SPP : 2560 / BF));   // symbols per round
     FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds;
@@ -1537,11 +1698,11 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     // 4 / 8, whose five- and ten-slice rounds are so short of scalar registers that the two extra live
     // values cost more than the saved traffic (+4 % at 6000 baud).
     constexpr bool HINT = !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
-    constexpr int kAlignMask = WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15));
+    constexpr int kAlignMask = GP ? 0 : (WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15)));   // GP reads 2-byte-aligned dwords
     const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
     const bool hinted = HINT && hint && aligned;
     if (hinted) {
-        constexpr int kRoundBytes = MULTI ? 1024 * MultiGeom<MULTI ? BF : 4>::R : (WM ? WmGeom<WM ? BF : 60>::RBYTES : 5120);
+        constexpr int kRoundBytes = MULTI ? 1024 * MultiGeom<MULTI ? BF : 4>::R : (WM ? WmGeom<WM ? BF : 60>::RBYTES : (GP ? GpGeom<GP ? BF : 128>::RBYTES : 5120));
         fr.request_probes((uint32_t)len * 2u, byte0, kRoundBytes);
     }
     // chunks entirely below the clock index are free already
@@ -1560,7 +1721,10 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         else if (HINT && BIG && hinted) FN<BF, FLAGS, true, HINT && BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
         else FN<BF, FLAGS, true, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
     } while (0)
-    if constexpr (WM) AFSK_ROUNDS(wm_rounds);
+    if constexpr (GP) {
+        if (HINT && BIG && hinted) gp_rounds<BF, FLAGS, HINT && BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+        else gp_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
+    } else if constexpr (WM) AFSK_ROUNDS(wm_rounds);
     else if constexpr (MULTI) AFSK_ROUNDS(multi_rounds);
     else AFSK_ROUNDS(fast_rounds);
 #undef AFSK_ROUNDS

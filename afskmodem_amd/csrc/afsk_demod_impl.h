@@ -194,6 +194,12 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 // every bit_frames with a compile-time geometry (everything else: the run-time geometry)
 #define AFSK_FAST_BF_LIST(X) X(4) X(8) X(12) X(16) X(20) X(24) X(32) X(40) X(48) X(60) X(64) X(80) X(96) X(100) X(120) X(160) X(240) X(320) X(480)
 
+// bit_frames with a compile-time geometry in the UNIFORM kernels only (general pieces, afsk_demod_fast.h):
+// the other values a Receiver can be built for -- 48000 / baud a divisor of 48000 and a multiple of 4 --
+// i.e. 375, 250, 240, 160, 125, 120, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25 and 24 baud.  In a
+// mixed-baud launch they run the run-time geometry (the per-stream switch stays at AFSK_FAST_BF_LIST).
+#define AFSK_GP_BF_LIST(X) X(128) X(192) X(200) X(300) X(384) X(400) X(500) X(600) X(640) X(800) X(960) X(1000) X(1200) X(1500) X(1600) X(1920) X(2000)
+
 __host__ __device__ constexpr bool bit_frames_valid(int bf) {       // ref:68-85, 327: templates exist, sync window fits
     return bf >= 4 && (bf & 3) == 0 && 2 * bf < kSync;
 }
@@ -202,6 +208,12 @@ __host__ __device__ constexpr bool has_fast_geometry(int bf) {
     AFSK_FAST_BF_LIST(AFSK_X)
 #undef AFSK_X
     return false;
+}
+__host__ __device__ constexpr bool has_uniform_geometry(int bf) {     // compile-time geometry in a uniform kernel
+#define AFSK_X(B) if (bf == B) return true;
+    AFSK_GP_BF_LIST(AFSK_X)
+#undef AFSK_X
+    return has_fast_geometry(bf);
 }
 
 // streams the decoder refuses before touching a sample: status 3 (invalid bit_frames; the host
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
 // a.uniform_bit_frames (host-validated: valid and without a compile-time geometry).
 template <int BF, int FLAGS = 0, bool BIG = false, int WPB = kWavesPerBlock>
 __global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) {
-    static_assert(BF == 0 || has_fast_geometry(BF), "no compile-time geometry for this bit_frames");
+    static_assert(BF == 0 || has_uniform_geometry(BF), "no compile-time geometry for this bit_frames");
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -9,8 +9,8 @@ JOBS=${AFSK_BUILD_JOBS:-$(nproc)}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
-# bit_frames values with a compile-time geometry = AFSK_FAST_BF_LIST in afsk_demod_impl.h; 0 = run-time geometry
-UNIFORM_BF=$(sed -n 's/^#define AFSK_FAST_BF_LIST(X)//p' afsk_demod_impl.h | tr -d 'X()' )
+# bit_frames values with a compile-time geometry = AFSK_FAST_BF_LIST + AFSK_GP_BF_LIST in afsk_demod_impl.h; 0 = run-time geometry
+UNIFORM_BF=$(sed -n 's/^#define AFSK_\(FAST\|GP\)_BF_LIST(X)//p' afsk_demod_impl.h | tr -d 'X()' | tr '\n' ' ')
 {
   # longest jobs first
   for f in afsk_demod_small afsk_demod_big; do echo "$f.o $f.hip"; done

@@ -817,7 +817,7 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
         for f in FIELDS:
             assert np.array_equal(getattr(got2, f), getattr(got, f)[sub]), f
         return
-    for baud in LARGE_LAUNCH_BAUDS + (150, 100, 250):
+    for baud in LARGE_LAUNCH_BAUDS + (150, 100, 375, 250, 240, 160, 120, 96, 80, 75, 48, 32, 24, 45):
         flat, off, ln, bf = large_launch_streams(n, (baud,), 1000 + baud)
         dev = "cuda:0"
         res = REAL_DEMOD_BATCH(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ln).to(dev),

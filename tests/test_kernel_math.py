@@ -158,3 +158,97 @@ def test_hamming_popcount_syndrome():
         s1 = bin(cw & 0x66).count("1") & 1
         s2 = bin(cw & 0x78).count("1") & 1
         assert pos == s2 * 4 + s1 * 2 + s0
+
+
+# ---- general-piece geometry (afsk_demod_fast.h GpGeom / gp_rounds) -----------------------------------
+GP_BFS = (128, 192, 200, 300, 384, 400, 500, 600, 640, 800, 960, 1000, 1200, 1500, 1600, 1920, 2000)
+
+
+def gp_geom(bf):
+    """GpGeom<BF> restated: lanes per symbol, and per lane (quarter k, first dword, dword count)."""
+    q = bf // 4
+    lps = 4
+    while lps < 64 and (64 // lps) * 2 * bf > 7680:
+        lps *= 2
+    lpq = lps // 4
+    qs = lambda k: (k * q + 1) // 2  # noqa: E731
+    lanes = []
+    for part in range(lps):
+        k, j = part // lpq, part % lpq
+        nk = qs(k + 1) - qs(k)
+        d0, d1 = qs(k) + (j * nk) // lpq, qs(k) + ((j + 1) * nk) // lpq
+        lanes.append((k, d0, d1 - d0))
+    return lps, lanes
+
+
+@pytest.mark.parametrize("bf", GP_BFS)
+def test_general_piece_map_covers_every_symbol_once(bf):
+    """gp_rounds: the LPS lanes of a symbol own disjoint runs of its bf/2 dwords, every lane NB + 1 or
+    NB + 2 of them, a run lies inside ONE quarter except that its last dword may straddle into the next
+    (odd quarter length), rounds are whole symbols of at most 7.5 KiB, a piece fits the 256-byte mirror."""
+    lps, lanes = gp_geom(bf)
+    q, d = bf // 4, bf // 2
+    assert 64 % lps == 0 and (64 // lps) * 2 * bf <= 7680
+    cover = np.zeros(d, int)
+    sizes = {n for _, _, n in lanes}
+    nb = min(sizes) - 1
+    assert nb >= 1 and sizes <= {nb + 1, nb + 2} and 4 * (nb + 2) + 4 <= 256
+    for k, d0, n in lanes:
+        cover[d0: d0 + n] += 1
+        first, last = 2 * d0, 2 * (d0 + n) - 1                  # first / last sample of the piece
+        assert first // q == k                                  # the piece starts in its quarter
+        assert (last - 1) // q == k                             # every sample but the very last one is in it
+        assert last // q in (k, k + 1) and last < bf
+    assert (cover == 1).all()
+
+
+@pytest.mark.parametrize("bf", GP_BFS)
+def test_general_piece_sums_equal_the_symbol_correlators(bf):
+    """gp_rounds arithmetic: NB dwords against the lane's constant template via ONE SAD against "hi"
+    (SAD against lo = 65535 * n - SAD against hi) + two tail slots with per-lane template dwords, summed
+    over the lanes, equals the mark and space SADs of ref:346-347 over the limited symbol."""
+    rng = np.random.default_rng(bf)
+    q, h = bf // 4, bf // 2
+    mark_t = np.array([65535 if ((j // q) & 1) == 0 else 0 for j in range(bf)])     # biased templates
+    space_t = np.array([65535 if j < h else 0 for j in range(bf)])
+    lps, lanes = gp_geom(bf)
+    nb = min(n for _, _, n in lanes) - 1
+    for _ in range(5):
+        lim = rng.choice([0, 0x8000, 0xFFFF], bf)                                  # limited samples, biased
+        want_m, want_s = np.abs(mark_t - lim).sum(), np.abs(space_t - lim).sum()
+        got_m = got_s = 0
+        for k, d0, n in lanes:
+            x = lim[2 * d0: 2 * (d0 + n)]
+            hsum = np.abs(65535 - x[: 2 * nb]).sum()
+            got_m += hsum if k % 2 == 0 else 65535 * 2 * nb - hsum
+            got_s += hsum if k < 2 else 65535 * 2 * nb - hsum
+            for dd in range(nb, n):                                                # tail slots A (and B)
+                lo, hi = 2 * (d0 + dd), 2 * (d0 + dd) + 1
+                is_last = dd == n - 1
+                kl = hi // q if is_last else k                                      # only the last dword can straddle
+                tm = (65535 if k % 2 == 0 else 0, 65535 if kl % 2 == 0 else 0)
+                ts = (65535 if k < 2 else 0, 65535 if kl < 2 else 0)
+                got_m += abs(tm[0] - lim[lo]) + abs(tm[1] - lim[hi])
+                got_s += abs(ts[0] - lim[lo]) + abs(ts[1] - lim[hi])
+        assert (got_m, got_s) == (want_m, want_s)
+
+
+@pytest.mark.parametrize("bf", (240, 300, 500, 1500, 2000))
+def test_sliding_correlation_identity_long_and_odd_quarters(bf):
+    """recover_clock_index_lane_steps for long templates: the 7-tap delta holds for any quarter length
+    (also odd ones: 75, 125, 375 samples), and floor(m / n) by the 2^36 magic multiplier is exact while
+    65535 * n^2 < 2^36 (n = 2 * bf <= 960); longer templates use the float estimate + fix-up."""
+    rng = np.random.default_rng(bf)
+    x = rng.integers(-32768, 32768, 4096 + 8, dtype=np.int64)
+    tc = training_cycle(bf)
+    n, q, h = 2 * bf, bf // 4, bf // 2
+    noff = 4096 - n
+    brute = np.array([np.abs(tc - x[i: i + n]).sum() for i in range(noff)])
+    i = np.arange(noff - 1)
+    delta = (x[i] - 2 * x[i + q] + 2 * x[i + 2 * q] - 2 * x[i + 3 * q] + 2 * x[i + bf]
+             - 2 * x[i + bf + h] + x[i + n])
+    assert np.array_equal(np.diff(brute), delta)
+    if 65535 * n * n < 2 ** 36:
+        mm = -(-2 ** 36 // n)
+        m = np.concatenate([rng.integers(0, 65535 * n + 1, 20000), [0, 65535 * n, n - 1, n, 65535 * n - 1]]).astype(object)
+        assert all(((int(v) * mm) >> 36) == int(v) // n for v in m)

@@ -27,4 +27,14 @@ if [ "${1:-}" = "prof" ]; then
     python tools/summarize_prof.py gpurun_out $w $steps 2>&1 | tail -40
     python tools/trace_timeline.py gpurun_out/prof_trace_$w 2>&1 | tee gpurun_out/timeline_$w.txt
   done
+  # the SURVEY 8(f) rows f1 / f2: one run of the config5 headline carrying both sub-records
+  w=next
+  rm -rf gpurun_out/prof_trace_$w gpurun_out/prof_pmc1_$w gpurun_out/prof_pmc2_$w
+  NX="--sub f1_modulate,f2_gate --steps 3 --warmup 1 --preroll-ms 0 --min-region-ms 0 --no-cpu-baseline --next-reps 20"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace_$w -- python3 $R/bench.py $NX 2>&1 | grep '^{"metric"' | tee $R/gpurun_out/prof_bench_$w.json | cut -c1-200 )
+  ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_pmc1_$w -- python3 $R/bench.py $NX --next-reps 4 2>&1 | tail -1 | cut -c1-100 )
+  ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_pmc2_$w -- python3 $R/bench.py $NX --next-reps 4 2>&1 | tail -1 | cut -c1-100 )
+  python tools/summarize_prof.py gpurun_out $w 20 --kernel modulate_kernel --name modulate 2>&1 | tail -30
+  python tools/summarize_prof.py gpurun_out $w 20 --kernel block_amp_kernel --name gate 2>&1 | tail -30
+  python tools/summarize_prof.py gpurun_out $w 20 --kernel gate_scan_kernel --name gate_scan 2>&1 | tail -12
 fi

@@ -6,7 +6,7 @@ import statistics
 import sys
 
 fs = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
-rows = [r for r in csv.DictReader(open(fs[0])) if "demod_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(fs[0])) if "demod_" in r["Kernel_Name"] and "kernel_t" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 gap = [int(b["Start_Timestamp"]) - int(a["End_Timestamp"]) for a, b in zip(rows, rows[1:])]
