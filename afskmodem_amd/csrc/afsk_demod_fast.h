@@ -187,6 +187,30 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18,448 B of LDS per wave
 
+// ---- register re-alignment helpers (phase A sub-windows, phase B pieces) ----
+// Re-align 24 dwords (six aligned 16-byte reads) by S bytes into 20 dwords.
+template <int S>
+__device__ __forceinline__ void realign(const uint32_t (&W)[24], uint32_t (&x)[20]) {
+    constexpr int A = S / 4, B = S % 4;
+#pragma unroll
+    for (int d = 0; d < 20; d++) {
+        if constexpr (B == 0) x[d] = W[d + A];
+        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
+    }
+}
+
+// Same for NI aligned dwords -> NO dwords (the 8-byte-aligned pieces of the 2400-baud mapping).
+template <int S, int NI, int NO>
+__device__ __forceinline__ void realign_n(const uint32_t (&W)[NI], uint32_t (&x)[NO]) {
+    constexpr int A = S / 4, B = S % 4;
+    static_assert(NO + A + (B ? 1 : 0) <= NI, "not enough input dwords");
+#pragma unroll
+    for (int d = 0; d < NO; d++) {
+        if constexpr (B == 0) x[d] = W[d + A];
+        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
+    }
+}
+
 // ---- phase A, lane-wise form (every single-pass bit_frames up to 120) --------------------
 // Every lane owns GC = 72 CONSECUTIVE sync offsets and the GC + 2*BF raw samples they touch,
 // loaded once from the ring into registers (14 / 19 / 29 ... 39 ds_read_b128 at bit_frames
@@ -356,26 +380,32 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
         const uint8_t* src = fr.ring + 2 * (STEP * t + GC * lane);
         constexpr int lag[7] = {0, Q, 2 * Q, 3 * Q, BF, BF + H, N};
         constexpr int coef[7] = {1, -2, 2, -2, 2, -2, 1};
+        // Sub-window e = the GC samples at lag[e] from the lane's first offset.  The lane base (48 bytes
+        // per lane) is 16-byte aligned; a lag that is not a multiple of 8 samples is served by the ALIGNED
+        // 64 bytes around it, re-aligned in registers by the compile-time shift (a 4-byte multiple is a
+        // register renaming, 2 bytes cost one v_alignbyte per dword) -- misaligned ds_read_b128 execute on
+        // gfx950 but several times slower (bit_frames 300 / 500: 78 -> 7x us per 4096 streams).
         uint32_t R[7][GC / 2];
+        static_for<0, 7>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            constexpr int S = (2 * lag[e]) % 16;
+            const uint8_t* p = src + 2 * lag[e] - S;
+            if constexpr (S == 0) {
 #pragma unroll
-        for (int e = 0; e < 7; e++) {
-#pragma unroll
-            for (int j = 0; j < GC / 8; j++) {
-                if constexpr (Q % 8 == 0) {
-                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 2 * lag[e] + 16 * j);
-                    R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
-                } else if constexpr (Q % 4 == 0) {   // lags are multiples of 8 bytes only (bit_frames 240: Q = 60)
-                    typedef u32x2 u32x2_al8 __attribute__((aligned(8)));
-                    const u32x2 ta = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j);
-                    const u32x2 tb = *reinterpret_cast<const u32x2_al8*>(src + 2 * lag[e] + 16 * j + 8);
-                    R[e][4 * j] = ta[0]; R[e][4 * j + 1] = ta[1]; R[e][4 * j + 2] = tb[0]; R[e][4 * j + 3] = tb[1];
-                } else {                              // any quarter length: 2-byte aligned sub-windows (gfx950 reads them)
-                    typedef u32x4 u32x4_al2 __attribute__((aligned(2)));
-                    const u32x4 t4 = *reinterpret_cast<const u32x4_al2*>(src + 2 * lag[e] + 16 * j);
+                for (int j = 0; j < GC / 8; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(p + 16 * j);
                     R[e][4 * j] = t4[0]; R[e][4 * j + 1] = t4[1]; R[e][4 * j + 2] = t4[2]; R[e][4 * j + 3] = t4[3];
                 }
+            } else {
+                uint32_t W[GC / 2 + 4];
+#pragma unroll
+                for (int j = 0; j < GC / 8 + 1; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(p + 16 * j);
+                    W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+                }
+                realign_n<S, GC / 2 + 4, GC / 2>(W, R[e]);
             }
-        }
+        });
         // run[k] = total(first + k + 1) - total(first)
         int32_t run[GC];
         int32_t acc = 0;
@@ -415,29 +445,6 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
 }
 
 // ------------------------------------------------------------------ phase B (fast)
-// Re-align 24 dwords (six aligned 16-byte reads) by S bytes into 20 dwords.
-template <int S>
-__device__ __forceinline__ void realign(const uint32_t (&W)[24], uint32_t (&x)[20]) {
-    constexpr int A = S / 4, B = S % 4;
-#pragma unroll
-    for (int d = 0; d < 20; d++) {
-        if constexpr (B == 0) x[d] = W[d + A];
-        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
-    }
-}
-
-// Same for NI aligned dwords -> NO dwords (the 8-byte-aligned pieces of the 2400-baud mapping).
-template <int S, int NI, int NO>
-__device__ __forceinline__ void realign_n(const uint32_t (&W)[NI], uint32_t (&x)[NO]) {
-    constexpr int A = S / 4, B = S % 4;
-    static_assert(NO + A + (B ? 1 : 0) <= NI, "not enough input dwords");
-#pragma unroll
-    for (int d = 0; d < NO; d++) {
-        if constexpr (B == 0) x[d] = W[d + A];
-        else x[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
-    }
-}
-
 // Sum over the dwords [D0, D1) of |0xFFFF - limited(x)| per 16-bit half: the SAD of the
 // limited samples against a "hi" (32767) template.  Against a "lo" (-32768) template the
 // SAD of the same samples is 65535 * n_samples minus this, so one v_sad_u16 per dword
