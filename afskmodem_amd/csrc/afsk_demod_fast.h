@@ -72,7 +72,9 @@ constexpr int kWarmMinStreams = 8192;
 // on the spot (and drops the hint), so results cannot change -- e.g. a weak signal below amp_end
 // with no loud probe at all still decodes, one demand fetch later.
 constexpr int kProbes = 64;               // one per lane; probes beyond the stream end cost nothing (range-checked)
-constexpr int kHintMinStreams = 6144;     // -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
+constexpr int kHintMinStreams = 6144;     // mixed-baud kernel: -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
+constexpr int kHintMinStreamsUniform = 4096;   // uniform kernels (no scalar-register pressure): -0.8 ... -1.6 % at 4096 streams and 1.02 x
+                                               // instead of 1.11 x the algorithmic bytes fetched; neutral at 2048
 
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len

@@ -295,22 +295,16 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
 // ---- one bit_frames for the whole launch (afsk_demod_batch_uniform) ------------------------------
 // BF > 0: the compile-time geometry of that value; BF == 0: the run-time geometry with
 // a.uniform_bit_frames (host-validated: valid and without a compile-time geometry).
-template <int BF, int FLAGS = 0, bool BIG = false, int WPB = kWavesPerBlock>
-__global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) {
-    static_assert(BF == 0 || has_uniform_geometry(BF), "no compile-time geometry for this bit_frames");
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = blockIdx.x * WPB + wave;
-    if (s >= a.n_streams) return;
+// one stream of a uniform launch, start to finish, by one wave
+template <int BF, int FLAGS, bool BIG>
+__device__ __forceinline__ void process_uniform_stream(const DemodArgs& a, int s, uint8_t* lds, int lane) {
     const int32_t len = a.stream_len[s];
     if (len < kSync) { store_refusal(a, s, lane, 1); return; }   // ref:323-325
     const int16_t* xs = a.samples + a.stream_offset[s];
     uint8_t* out_row = a.out_bytes + (int64_t)s * a.out_stride;
-    uint8_t* lds = lds_all + wave * kFastWaveLdsProduct;
     int32_t* margins = a.out_margins ? a.out_margins + (int64_t)s * a.margin_stride : nullptr;
     const bool warm = a.n_streams >= kWarmMinStreams;
-    const bool hint = a.n_streams >= kHintMinStreams;
+    const bool hint = a.n_streams >= kHintMinStreamsUniform;
     RxState st;
     int32_t n_sym = 0;
     int ci = 0;
@@ -331,6 +325,17 @@ __global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) 
     if constexpr (FLAGS & 64) {
         if (lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <int BF, int FLAGS = 0, bool BIG = false, int WPB = kWavesPerBlock>
+__global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) {
+    static_assert(BF == 0 || has_uniform_geometry(BF), "no compile-time geometry for this bit_frames");
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = blockIdx.x * WPB + wave;
+    if (s >= a.n_streams) return;
+    process_uniform_stream<BF, FLAGS, BIG>(a, s, lds_all + wave * kFastWaveLdsProduct, lane);
 }
 
 }  // namespace afsk

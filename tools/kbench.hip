@@ -46,10 +46,48 @@ static void launch_uflags(const DemodArgs& a, hipStream_t s) {
     const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
     DemodArgs b = a;
     b.uniform_bit_frames = KBENCH_BF;
-    if (a.n_streams >= afsk::kHintMinStreams)
+    if (a.n_streams >= afsk::kHintMinStreamsUniform)
         hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
     else
         hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
+}
+
+// ---- persistent grids around the uniform body (experiments; NOT in the product) ------------------------
+// 2 blocks per CU, every wave loops over streams: STEAL = false: s = wave id, += number of waves (static
+// striding); STEAL = true: one atomicAdd on a global counter per claimed stream (work stealing).
+template <bool STEAL, bool BIG>
+__global__ __launch_bounds__(64 * afsk::kWavesPerBlock) void persistent_uniform_kernel(DemodArgs a, unsigned* counter) {
+    using namespace afsk;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kFastWaveLdsProduct];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint8_t* lds = lds_all + wave * kFastWaveLdsProduct;
+    const int total = gridDim.x * kWavesPerBlock;
+    int s = blockIdx.x * kWavesPerBlock + wave;
+    for (int it = 0; it < (1 << 20); it++) {   // (bounded on top of the exit condition every wave reaches)
+        if constexpr (STEAL) {
+            unsigned v = 0;
+            if (lane == 0) v = atomicAdd(counter, 1u);
+            s = (int)__builtin_amdgcn_readfirstlane(v);
+        }
+        if (s >= a.n_streams) break;
+        process_uniform_stream<KBENCH_BF, 0, BIG>(a, s, lds, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (!STEAL) s += total;
+    }
+}
+static unsigned* g_counters = nullptr;       // zeroed once; every launch takes the next one
+static int g_counter_next = 0;
+template <bool STEAL>
+static void launch_persistent(const DemodArgs& a, hipStream_t s) {
+    DemodArgs b = a;
+    b.uniform_bit_frames = KBENCH_BF;
+    const int blocks = std::min((a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock, 512);
+    unsigned* c = g_counters + (g_counter_next++ & 16383);
+    if (a.n_streams >= afsk::kHintMinStreamsUniform)
+        hipLaunchKernelGGL((persistent_uniform_kernel<STEAL, true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b, c);
+    else
+        hipLaunchKernelGGL((persistent_uniform_kernel<STEAL, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b, c);
 }
 
 // same kernel over 4 rotating copies of the input (1.6 GB working set at 4096 streams): defeats
@@ -157,6 +195,9 @@ int main(int argc, char** argv) {
         vs.push_back({"uniform skip_sync", launch_uflags<1>, true});
         vs.push_back({"uniform skip_valu", launch_uflags<2>, false});
         vs.push_back({"uniform skip_sync+valu", launch_uflags<3>, false});
+        CK(hipMalloc(&g_counters, 16384 * sizeof(unsigned))); CK(hipMemset(g_counters, 0, 16384 * sizeof(unsigned)));
+        vs.push_back({"persistent, static stride", launch_persistent<false>, true});
+        vs.push_back({"persistent, work stealing", launch_persistent<true>, true});
     }
     if (bfv == KBENCH_BF)
     {   // timeline of one launch of the diagnostic (stamped) build
