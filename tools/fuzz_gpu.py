@@ -1,5 +1,7 @@
 """Randomised GPU-vs-oracle comparison, larger than the test suite's (diagnostic).
-   python tools/fuzz_gpu.py [streams_per_config=3000] [seed=1]
+   python tools/fuzz_gpu.py [streams_per_config=3000] [seed=1] [entries=uniform,mixed]
+Every batch goes through BOTH device entries (afsk_demod_batch_uniform: one kernel per bit_frames;
+afsk_demod_batch: the mixed-baud kernel with bit_frames per stream) unless the third argument names one.
 Random-noise streams (uniformly distributed clock indices, chance terminators and squelch
 stops), bursts spliced at random offsets, every single-pass baud rate plus generic ones,
 random stream offsets (2-byte alignment) and squelch thresholds."""
@@ -17,11 +19,13 @@ from oracle import afsk_oracle as O  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+entries = (sys.argv[3] if len(sys.argv) > 3 else "uniform,mixed").split(",")
 rng = np.random.default_rng(seed)
 FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
 total_bad = 0
+# every rate a Receiver can be built for (36 values of bit_frames)
 for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400, 375, 250, 240, 200,
-             160, 150, 125, 120, 100, 96, 75, 50, 32, 24):
+             160, 150, 125, 120, 100, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25, 24):
     bf = 48000 // baud
     burst = O.wav_convert(O.get_frames(bytes(rng.integers(0, 256, 3, dtype=np.uint8)), baud, 0.03))
     pieces = []
@@ -54,35 +58,37 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
         t0 = time.time()
         want = O.demod_batch(flat, off, ln, bfa, amp_end, out_stride=64, n_threads=os.cpu_count() or 8)
         x = torch.from_numpy(flat).cuda()
-        res = batch.demod_batch(x, torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), bfa, amp_end,
-                                out_stride=64)
-        torch.cuda.synchronize()
-        got = res.cpu()
-        bad = 0
-        for f in FIELDS:
-            bad += int((getattr(got, f) != want[f]).sum())
-        nb = np.minimum(want["nbytes"], 64)
-        mask = np.arange(64)[None, :] < nb[:, None]
-        bad += int(((got.bytes != want["bytes"]) & mask).any(axis=1).sum())
+        d_off, d_ln = torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda()
         late = int((want["clock_idx"] >= 4096 - 2 * bf - 72).sum())
-        print(f"baud {baud:5d} amp_end {amp_end:5d}: {len(pieces)} streams, mismatching fields {bad}, "
-              f"decoding {int((want['nbits'] > 0).sum())}, clock idx in the last 72 offsets {late} "
-              f"({time.time() - t0:.1f} s)", flush=True)
-        total_bad += bad
-        if amp_end == 14000:          # soft outputs (afsk_demod_batch_ex) on a slice of the batch
+        for entry in entries:
+            res = batch.demod_batch(x, d_off, d_ln, bf if entry == "uniform" else bfa, amp_end, out_stride=64, entry=entry)
+            torch.cuda.synchronize()
+            got = res.cpu()
+            bad = 0
+            for f in FIELDS:
+                bad += int((getattr(got, f) != want[f]).sum())
+            nb = np.minimum(want["nbytes"], 64)
+            mask = np.arange(64)[None, :] < nb[:, None]
+            bad += int(((got.bytes != want["bytes"]) & mask).any(axis=1).sum())
+            print(f"baud {baud:5d} amp_end {amp_end:5d} {entry:7s}: {len(pieces)} streams, mismatching fields {bad}, "
+                  f"decoding {int((want['nbits'] > 0).sum())}, clock idx in the last 72 offsets {late} "
+                  f"({time.time() - t0:.1f} s)", flush=True)
+            total_bad += bad
+        if amp_end == 14000:          # soft outputs on a slice of the batch
             m = min(400, len(pieces))
             ms = int(ln.max()) // bf + 1
             soft = O.demod_batch_soft(flat, off[:m], ln[:m], bfa[:m], amp_end, out_stride=64, margin_stride=ms)
-            r2 = batch.demod_batch(x, torch.from_numpy(off[:m]).cuda(), torch.from_numpy(ln[:m]).cuda(), bfa[:m],
-                                   amp_end, out_stride=64, diagnostics=True, margin_stride=ms)
-            torch.cuda.synchronize()
-            corr = r2.corrected.cpu().numpy()
-            marg = r2.margins.cpu().numpy()
-            nsym = soft["n_symbols"]
-            mask = np.arange(ms)[None, :] < np.minimum(nsym, ms)[:, None]
-            sbad = int((corr != soft["corrected"]).sum()) + int(((marg != soft["margins"]) & mask).any(axis=1).sum())
-            print(f"           soft outputs on {m} streams: mismatches {sbad} "
-                  f"(corrected codewords up to {int(soft['corrected'].max())})", flush=True)
-            total_bad += sbad
+            for entry in entries:
+                r2 = batch.demod_batch(x, d_off[:m].contiguous(), d_ln[:m].contiguous(), bf if entry == "uniform" else bfa[:m],
+                                       amp_end, out_stride=64, diagnostics=True, margin_stride=ms, entry=entry)
+                torch.cuda.synchronize()
+                corr = r2.corrected.cpu().numpy()
+                marg = r2.margins.cpu().numpy()
+                nsym = soft["n_symbols"]
+                mask = np.arange(ms)[None, :] < np.minimum(nsym, ms)[:, None]
+                sbad = int((corr != soft["corrected"]).sum()) + int(((marg != soft["margins"]) & mask).any(axis=1).sum())
+                print(f"           soft outputs on {m} streams ({entry}): mismatches {sbad} "
+                      f"(corrected codewords up to {int(soft['corrected'].max())})", flush=True)
+                total_bad += sbad
 print("TOTAL MISMATCHES", total_bad)
 sys.exit(1 if total_bad else 0)
