@@ -1,4 +1,5 @@
-"""GPU vs oracle on long streams at every single-pass baud rate (diagnostic)."""
+"""GPU vs oracle on long streams (many ring laps, several deferred ECC flushes) at every rate a Receiver
+can be built for, through both device entries (diagnostic)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,10 @@ bad = 0
 for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 2500, True), (3000, 2000, True), (2400, 1800, True),
                             (2000, 1500, True), (1500, 1200, True), (1000, 800, True), (750, 600, True), (600, 500, True), (300, 260, True),
                             (800, 650, True), (500, 420, True), (480, 400, True), (400, 340, True),
-                            (375, 320, True), (250, 220, True), (200, 170, True), (160, 130, True), (100, 90, True)):
+                            (375, 320, True), (250, 220, True), (240, 200, True), (200, 170, True), (160, 130, True), (150, 125, True),
+                            (125, 105, True), (120, 100, True), (100, 90, True), (96, 80, True), (80, 70, True), (75, 66, True),
+                            (60, 50, True), (50, 44, True), (48, 40, True), (40, 36, True), (32, 28, True), (30, 26, True),
+                            (25, 22, True), (24, 20, True)):
     bf = 48000 // baud
     pieces = []
     for k in range(6):
@@ -26,13 +30,15 @@ for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 250
     flat = np.concatenate(pieces)
     stride = int(nbytes + 64)
     want = O.demod_batch(flat, off, ln, np.full(6, bf, np.int32), 14000, out_stride=stride, n_threads=6)
-    res = batch.demod_batch(torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), bf, 14000, out_stride=stride).cpu()
     b = 0
-    for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"):
-        b += int((getattr(res, f) != want[f]).sum())
-    for i in range(6):
-        nb = min(int(want["nbytes"][i]), stride)
-        b += int((res.bytes[i, :nb] != want["bytes"][i, :nb]).any())
+    for entry in ("uniform", "mixed"):
+        res = batch.demod_batch(torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(),
+                                bf if entry == "uniform" else np.full(6, bf, np.int32), 14000, out_stride=stride, entry=entry).cpu()
+        for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"):
+            b += int((getattr(res, f) != want[f]).sum())
+        for i in range(6):
+            nb = min(int(want["nbytes"][i]), stride)
+            b += int((res.bytes[i, :nb] != want["bytes"][i, :nb]).any())
     print(baud, "samples", int(ln.max()), "nbytes", want["nbytes"].tolist(), "mismatches", b, flush=True)
     bad += b
 print("TOTAL", bad)
