@@ -17,6 +17,7 @@ OK = 0
 E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP, E_HOST = -1, -2, -3, -4, -5
 ST_OK, ST_TOO_SHORT, ST_NO_DATA, ST_INVALID_BAUD = 0, 1, 2, 3
 WAV_OK = 0
+WAV_SLOT = 5
 
 SAMPLE_RATE = 48000
 SYNC_WINDOW = 4096
@@ -62,6 +63,9 @@ SIGNATURES = {
                                           _u8p, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "afsk_host_scratch_release": (C.c_int, []),
     "afsk_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p, _i64p, _i32p]),
+    "afsk_file_sizes": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p]),
+    "afsk_wav_ingest": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p, _i64p, C.c_void_p, C.c_int64,
+                                  _i64p, _i64p, _i32p]),
     "afsk_wav_upload": (C.c_int, [C.POINTER(C.c_char_p), _i64p, _i64p, _i64p, C.c_int32, C.c_void_p,
                                   C.c_int64]),
     "afsk_modulate_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -418,13 +418,16 @@ def wav_probe(filenames):
 def load_wav_batch(filenames, device="cuda:0"):
     """Many .wav files -> the stream-major device layout.
 
-    ``afsk_wav_probe`` finds every file's data chunk, ``afsk_wav_upload`` preads the chunks
-    straight into the library's pinned staging windows and streams them to one device buffer:
-    one host copy per byte, no Python object per file beyond its name.  Like the reference
-    (ref:213-217) the header's rate / width / channel count are not interpreted.  A file the
-    native walk does not accept as plain PCM RIFF is opened with the stdlib reader instead, so the
-    caller gets the reference's own exception (or its data).  Returns (samples, stream_offset,
-    stream_len, max_len) like ``upload_streams``; streams start on 16-byte boundaries."""
+    One pass per file (r3): ``afsk_file_sizes`` (a parallel ``stat``) bounds every file's data chunk,
+    which fixes the device layout before any file is opened; ``afsk_wav_ingest`` then opens each file
+    once, walks its chunks like the stdlib reader the reference calls (ref:214), preads the data chunk
+    straight into the library's pinned staging buffers and closes it, pipelined against the H2D
+    copies: one host copy per byte, no Python object per file beyond its name.  Like the reference
+    (ref:213-217) the header's rate / width / channel count are not interpreted.  A file the native
+    walk does not accept as plain PCM RIFF is opened with the stdlib reader instead, so the caller
+    gets the reference's own exception (or its data).  Returns (samples, stream_offset, stream_len,
+    max_len) like ``upload_streams``; streams start on 16-byte boundaries (a stream is followed by
+    the few zero samples its file's header left in its slot)."""
     torch = _torch()
     _native.require_device()
     names = list(filenames)
@@ -432,40 +435,52 @@ def load_wav_batch(filenames, device="cuda:0"):
         return upload_streams([], device)
     n = len(names)
     enc, arr = _c_names(names)
-    d_off, d_bytes, status = _wav_probe_c(arr, n)
-    odd = {}                                         # index -> frames read by the stdlib reader
-    for i in np.nonzero(status != _native.WAV_OK)[0]:
-        odd[int(i)] = read_wav_frames(names[int(i)])     # raises what the reference raises
-        d_bytes[i] = 2 * len(odd[int(i)])
-    lens = (d_bytes // 2).astype(np.int64)
-    if int(lens.max()) > _native.MAX_STREAM_LEN:
+    lib = _native.lib()
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
+    sizes = np.zeros(n, np.int64)
+    _native.check(lib.afsk_file_sizes(arr, n, p64(sizes)))
+    slot = ((np.maximum(sizes, 0) // 2) + 7) & ~np.int64(7)     # samples reserved per file, 16-byte granules
+    if int(slot.max()) > _native.MAX_STREAM_LEN:
         raise ValueError("a stream longer than AFSK_MAX_STREAM_LEN samples")
-    padded = (lens + 7) & ~np.int64(7)               # every stream starts on a 16-byte boundary
     offs = np.zeros(n, np.int64)
-    offs[1:] = np.cumsum(padded[:-1])
-    total = int(offs[-1] + lens[-1])
+    offs[1:] = np.cumsum(slot[:-1])
+    total = int(offs[-1] + slot[-1])
     samples = torch.empty(max(total, 1), dtype=torch.int16, device=device)
     if total == 0:
         samples.zero_()
-    keep = np.nonzero((status == _native.WAV_OK) & (lens > 0))[0]
-    if keep.size:
-        # afsk_wav_upload fills `samples` on the library's private non-blocking stream, which is not
-        # ordered against torch's streams: the caching allocator may have handed out a block that
-        # kernels still in flight on the current stream read (e.g. the previous batch's asynchronous
-        # demod_batch followed by `del`), so those must have finished before the DMA overwrites it
-        torch.cuda.current_stream(samples.device).synchronize()
-        with torch.cuda.device(samples.device):
-            if keep.size == n:                       # the usual case: every file is plain PCM RIFF
-                k_arr, k_off, k_bytes, k_dst = arr, d_off, d_bytes, offs
+    d_off = np.zeros(n, np.int64)
+    d_bytes = np.zeros(n, np.int64)
+    status = np.zeros(n, np.int32)
+    # afsk_wav_ingest fills `samples` on the library's private non-blocking stream, which is not
+    # ordered against torch's streams: the caching allocator may have handed out a block that
+    # kernels still in flight on the current stream read (e.g. the previous batch's asynchronous
+    # demod_batch followed by `del`), so those must have finished before the DMA overwrites it
+    torch.cuda.current_stream(samples.device).synchronize()
+    with torch.cuda.device(samples.device):
+        _native.check(lib.afsk_wav_ingest(arr, n, p64(offs), p64(slot), samples.data_ptr(), int(samples.numel()),
+                                          p64(d_off), p64(d_bytes), status.ctypes.data_as(C.POINTER(C.c_int32))))
+    lens = (d_bytes // 2).astype(np.int64)
+    bad = np.nonzero(status != _native.WAV_OK)[0]
+    if bad.size:
+        lens[bad] = 0
+        late = []                                    # (index, frames) that do not fit their slot: appended behind the batch
+        for i in bad:
+            fr = read_wav_frames(names[int(i)])          # raises what the reference raises
+            lens[i] = len(fr)
+            if len(fr) <= int(slot[i]):
+                if len(fr):
+                    samples[int(offs[i]): int(offs[i]) + len(fr)] = torch.from_numpy(np.ascontiguousarray(fr)).to(device)
             else:
-                k_arr = (C.c_char_p * keep.size)(*[enc[int(i)] for i in keep])
-                k_off, k_bytes, k_dst = (np.ascontiguousarray(a[keep]) for a in (d_off, d_bytes, offs))
-            p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
-            _native.check(_native.lib().afsk_wav_upload(k_arr, p(k_off), p(k_bytes), p(k_dst), int(keep.size),
-                                                        samples.data_ptr(), int(samples.numel())))
-    for i, fr in odd.items():
-        if len(fr):
-            samples[int(offs[i]): int(offs[i]) + len(fr)] = torch.from_numpy(np.ascontiguousarray(fr)).to(device)
+                late.append((int(i), fr))
+        if late:                                     # (a reader that returns more frames than the file has bytes: not expected)
+            extra = torch.from_numpy(np.concatenate([np.ascontiguousarray(fr) for _, fr in late])).to(device)
+            pos = total
+            samples = torch.cat([samples[:total], extra])
+            for i, fr in late:
+                offs[i] = pos
+                pos += len(fr)
+    if int(lens.max()) > _native.MAX_STREAM_LEN:
+        raise ValueError("a stream longer than AFSK_MAX_STREAM_LEN samples")
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     return samples, t(offs), t(lens.astype(np.int32)), int(lens.max())
 

@@ -741,7 +741,8 @@ def measure_gate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dic
 
 def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
     """n .wav files (SoundInput.loadFromFile ref:213-217) -> the stream-major
-    device layout (afsk_wav_probe + afsk_wav_upload), then decoded by Receiver.load_batch.
+    device layout (afsk_file_sizes + afsk_wav_ingest: one open / header walk / pread / close per file,
+    pipelined against the H2D copies), then decoded by Receiver.load_batch.
     PCIe-bound: measured against ONE pinned hipMemcpy of the same byte count on this box."""
     import shutil
     import tempfile
@@ -784,7 +785,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         ok = sum(decoded[i] == payloads[i % 16] for i in range(n_files))
         avg, med = sum(ing) / len(ing), median(ing)
         peak = total_bytes / min(pc) / 1e9
-        rec = {"row": "f3 .wav ingest (afsk_wav_probe + afsk_wav_upload)", "files": n_files,
+        rec = {"row": "f3 .wav ingest (afsk_file_sizes + afsk_wav_ingest: one pass per file)", "files": n_files,
                "bytes": total_bytes, "reps": reps, "unit": "files/s", "value": round(n_files / med),
                "ingest_ms": {"median": round(med * 1e3, 3), "best": round(min(ing) * 1e3, 3)},
                "pinned_hipMemcpy_ms": round(min(pc) * 1e3, 3),
@@ -796,7 +797,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                             "kernel_ms_median": round(med * 1e3, 3),
                             "frac_at_median": round(total_bytes / med / 1e9 / peak, 4),
                             "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
-                                          "run (best of %d); the ingest also opens, probes, preads and closes every file "
+                                          "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
                                           "(page cache warm: the files were just written)" % reps},
                "host_cores": os.cpu_count(), "files_on": d.split(os.sep)[1] if os.sep in d else d}
         del pin, devbuf

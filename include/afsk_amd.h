@@ -202,11 +202,34 @@ int afsk_host_scratch_release(void);
 #define AFSK_WAV_NOT_RIFF 2    /* no 'RIFF' .. 'WAVE' header                              */
 #define AFSK_WAV_NO_DATA 3     /* 'fmt ' and/or 'data' chunk missing, or 'data' first     */
 #define AFSK_WAV_FORMAT 4      /* format tag other than PCM, zero channels / sample width */
+#define AFSK_WAV_SLOT 5        /* afsk_wav_ingest only: the data does not fit the caller's slot    */
 int afsk_wav_probe(const char *const *paths, int32_t n_files, int64_t *out_data_offset,
                    int64_t *out_data_bytes, int32_t *out_status);
 int afsk_wav_upload(const char *const *paths, const int64_t *data_offset, const int64_t *data_bytes,
                     const int64_t *stream_offset, int32_t n_files, int16_t *d_samples,
                     int64_t capacity_samples);
+
+/*
+ * The same ingest in ONE pass per file (what batch.load_wav_batch uses since r3):
+ *
+ * afsk_file_sizes  st_size of every file (-1: cannot stat), host-only, parallel.  A file's data chunk
+ *   cannot be longer than the file, so the sizes give a device layout BEFORE any file is opened:
+ *   slot i = the device range reserved for file i (slot_offset[i], slot_samples[i], in samples).
+ * afsk_wav_ingest  per file: open, the chunk walk of afsk_wav_probe, pread of the data chunk straight
+ *   into pinned memory, close -- pipelined against the H2D copies (four 16 MiB staging buffers; pool
+ *   threads fill, the calling thread sends).  out_data_offset / out_data_bytes / out_status as
+ *   afsk_wav_probe; the stream of file i is d_samples[slot_offset[i] .. + out_data_bytes[i] / 2).
+ *   Device bytes written: every slot in full (the data, then zeros) and gaps of at most 256 bytes
+ *   between consecutive slots (zeros); a file whose status is not AFSK_WAV_OK -- or whose data would not
+ *   fit its slot: AFSK_WAV_SLOT -- leaves a zeroed slot for the caller to fill (batch.load_wav_batch
+ *   re-opens it with the stdlib reader, so the caller sees the reference's own exception or data).
+ *   Slots ascending, non-overlapping, inside capacity_samples.  Synchronous for the caller, on the
+ *   calling thread's private non-blocking stream (same ordering contract as afsk_wav_upload); fork-safe.
+ */
+int afsk_file_sizes(const char *const *paths, int32_t n_files, int64_t *out_size_bytes);
+int afsk_wav_ingest(const char *const *paths, int32_t n_files, const int64_t *slot_offset,
+                    const int64_t *slot_samples, int16_t *d_samples, int64_t capacity_samples,
+                    int64_t *out_data_offset, int64_t *out_data_bytes, int32_t *out_status);
 
 /*
  * On-device input synthesis: Transmitter.__getFrames (:452-469) with ECC.encode

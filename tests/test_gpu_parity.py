@@ -674,6 +674,24 @@ def test_wav_batch_ingest_and_load_batch(torch_cuda, tmp_path):
     for i, fn in enumerate(names):
         want = np.asarray(afskmodem.SoundInput.loadFromFile(fn), np.int16)
         o = int(off[i]); assert np.array_equal(h[o: o + int(ln[i])], want), i
+    # the two-call form of the C-ABI (afsk_wav_probe, then afsk_wav_upload into a layout of the caller's choosing)
+    import ctypes
+    d_off, d_bytes, st = batch.wav_probe(names)
+    assert (st == 0).all() and np.array_equal(d_bytes // 2, ln.cpu().numpy())
+    lens2 = d_bytes // 2
+    offs2 = np.zeros(len(names), np.int64)
+    offs2[1:] = np.cumsum(((lens2 + 7) & ~7)[:-1] + 400)          # 800-byte gaps: never written
+    buf = torch.full((int(offs2[-1] + lens2[-1]) + 8,), 77, dtype=torch.int16, device="cuda:0")
+    arr = (ctypes.c_char_p * len(names))(*[os.fsencode(f) for f in names])
+    p64 = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))  # noqa: E731
+    torch.cuda.synchronize()
+    _native.check(_native.lib().afsk_wav_upload(arr, p64(d_off), p64(d_bytes), p64(offs2), len(names), buf.data_ptr(), buf.numel()))
+    hb = buf.cpu().numpy()
+    for i, fn in enumerate(names):
+        o = int(offs2[i])
+        assert np.array_equal(hb[o: o + int(lens2[i])], h[int(off[i]): int(off[i]) + int(ln[i])]), i
+        if i + 1 < len(names):
+            assert (hb[int(offs2[i + 1]) - 300: int(offs2[i + 1])] == 77).all(), i      # the caller's gap is untouched
     afskmodem.LOG_LEVEL = 5
     r = afskmodem.Receiver(1200)
     got = r.load_batch(names)

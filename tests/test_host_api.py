@@ -218,6 +218,10 @@ def test_cabi_argument_checks_new_entries():
     assert lib.afsk_wav_probe(None, 0, None, None, None) == 0
     assert lib.afsk_wav_upload(None, None, None, None, 0, None, 0) == 0
     assert lib.afsk_wav_upload(None, None, None, None, 3, None, 10) == _native.E_INVALID_ARG
+    assert lib.afsk_file_sizes(None, 0, None) == 0 and lib.afsk_file_sizes(None, -1, None) == _native.E_INVALID_ARG
+    assert lib.afsk_file_sizes(None, 2, None) == _native.E_INVALID_ARG
+    assert lib.afsk_wav_ingest(None, 0, None, None, None, 0, None, None, None) == 0
+    assert lib.afsk_wav_ingest(None, 3, None, None, None, 10, None, None, None) == _native.E_INVALID_ARG
     null = (ctypes.c_void_p * 1)(None)
     assert lib.afsk_demod_streams_host(null, p(ln, ctypes.c_int32), p(bf, ctypes.c_int32), 14000, 1,
                                        *outs) == _native.E_INVALID_ARG
@@ -235,6 +239,21 @@ def test_cabi_argument_checks_new_entries():
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, -1, *u_tail) == _native.E_INVALID_ARG
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 0, *u_tail) == 0
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 4, *u_tail) == _native.E_INVALID_ARG   # null pointers
+
+
+def test_file_sizes_entry(tmp_path):
+    """afsk_file_sizes (host-only): st_size per file, -1 for a file that cannot be stat'ed."""
+    names = []
+    for i, nbytes in enumerate((0, 1, 44, 96044)):
+        fn = str(tmp_path / f"s{i}.bin")
+        with open(fn, "wb") as f:
+            f.write(b"x" * nbytes)
+        names.append(fn)
+    names.append(str(tmp_path / "missing.bin"))
+    arr = (ctypes.c_char_p * len(names))(*[os.fsencode(f) for f in names])
+    out = np.zeros(len(names), np.int64)
+    assert _native.lib().afsk_file_sizes(arr, len(names), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))) == 0
+    assert out.tolist() == [0, 1, 44, 96044, -1]
 
 
 def test_wav_probe_survives_fork(tmp_path):
