@@ -9,16 +9,15 @@
 
 template <int BF>
 __global__ __launch_bounds__(64) void k_sync(const int16_t* xs, int32_t len, uint32_t* dbg, int* ci_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[afsk::kFastWaveLds];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[afsk::kFastWaveLdsProduct];
     afsk::FastRing fr;
     fr.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, len * 2, 0x00020000);
     fr.ring = lds; fr.lane = threadIdx.x;
-    using G = afsk::SyncGeom<BF>;
-    for (int c = 0; c < G::SYNC_CHUNKS; c++) fr.issue(c);
-    fr.next = G::SYNC_CHUNKS;
+    for (int c = 0; c < afsk::kRingChunks; c++) fr.issue(c);
+    fr.next = afsk::kRingChunks;
     int ci;
-    if constexpr (BF <= 80) ci = afsk::recover_clock_index_lanes<BF, true, G::SYNC_CHUNKS>(fr, dbg);
-    else ci = afsk::recover_clock_index_lane_steps<BF, true, G::SYNC_CHUNKS>(fr, dbg);
+    if constexpr (BF <= 120) ci = afsk::recover_clock_index_lanes<BF, true>(fr, dbg);          // contiguous lane windows
+    else ci = afsk::recover_clock_index_lane_steps<BF, true>(fr, dbg);                        // sub-windows in steps
     afsk::wait_vmcnt<0>();
     if (threadIdx.x == 0) *ci_out = ci;
 }
@@ -53,6 +52,7 @@ int main() {
     unsigned s = 12345;
     for (auto& v : x) { s = s * 1664525u + 1013904223u; v = (int16_t)(s >> 16); }
     run<20>(x); run<40>(x); run<80>(x); run<160>(x);
+    run<100>(x); run<120>(x); run<240>(x); run<300>(x); run<320>(x); run<480>(x); run<500>(x); run<1500>(x); run<2000>(x);   // long / odd quarter lengths
     // a Transmitter-like stream: clean training cycles (many equal minima, first one wins)
     for (size_t i = 0; i < x.size(); i++) { int ph = (int)(i % 80); x[i] = ph < 40 ? (((ph / 10) & 1) ? -32768 : 32767) : (ph < 60 ? 32767 : -32768); }
     run<40>(x);
