@@ -987,7 +987,7 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
             const size_t b0 = (size_t)slot_offset[s] * 2, cap = (size_t)slot_samples[s] * 2;
             if (cap == 0) {                           // nothing to copy, but the file is still probed
                 if (!open_w) { w_b0 = w_b1 = b0; open_w = true; }
-                pieces.push_back({s, wins.size(), 0, 0, b0 >= w_b0 ? b0 - w_b0 : 0});
+                pieces.push_back({s, wins.size(), 0, 0, 0});
                 continue;
             }
             size_t done = 0;
