@@ -772,7 +772,8 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                 ts.append(time.perf_counter() - t0)
             return ts
 
-        batch.load_wav_batch(names[:64], ctx.dev)                  # warm: library, pinned windows
+        batch.load_wav_batch(names, ctx.dev)                       # warm, untimed: I/O pool, pinned buffers, torch's
+        torch.cuda.synchronize()                                   # allocator (a first 393 MB block is a hipMalloc)
         ing = timed(lambda: batch.load_wav_batch(names, ctx.dev))
         pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
         devbuf = torch.empty(total_bytes // 2, dtype=torch.int16, device=ctx.dev)
@@ -791,11 +792,11 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                "pinned_hipMemcpy_ms": round(min(pc) * 1e3, 3),
                "load_batch_end_to_end_ms": {"median": round(median(e2e) * 1e3, 3), "best": round(min(e2e) * 1e3, 3)},
                "decoded_match_rate": ok / n_files,
-               "roofline": {"bound": "pcie", "achieved": round(total_bytes / avg / 1e9, 2), "peak": round(peak, 2),
-                            "unit": "GB/s", "frac": round(total_bytes / avg / 1e9 / peak, 4), "traffic": None,
-                            "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(avg * 1e3, 3),
-                            "kernel_ms_median": round(med * 1e3, 3),
-                            "frac_at_median": round(total_bytes / med / 1e9 / peak, 4),
+               # host-side wall times (Python + syscalls + H2D): the MEDIAN call is the figure, the mean rides along
+               "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2),
+                            "unit": "GB/s", "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
+                            "kernel_ms_mean": round(avg * 1e3, 3),
                             "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
                                           "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
                                           "(page cache warm: the files were just written)" % reps},
