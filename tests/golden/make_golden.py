@@ -382,6 +382,33 @@ def main():
         x = O.add_noise(np.zeros(total, np.int16), seed=4343, stream_idx=baud, scale_q24=1 << 22)
         add_case(f"r2/garbage/{baud}", x.tolist(), baud,
                  gen={"kind": "garbage", "total": total, "seed": 4343, "stream_idx": baud, "scale_q24": 1 << 22})
+    # appended in round 3 (fresh generator): the 17 remaining rates a Receiver can be built for
+    # (48000 / baud a divisor of 48000 and a multiple of 4) -- 375 ... 24 baud, the general-piece
+    # geometries of the uniform kernels (quarter lengths like 75, 125 or 375 samples) -- so that EVERY
+    # compile-time geometry is pinned by the reference itself: clean, with a leading offset (odd and
+    # even), noisy, and one garbage stream each
+    rng5 = np.random.default_rng(20261004)
+    for baud in (375, 250, 240, 160, 125, 120, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25, 24):
+        bf = 48000 // baud
+        data = rng5.integers(0, 256, 3 if bf < 1000 else 2, dtype=np.uint8).tobytes()
+        tt = max(0.1, 8.0 / baud)                    # >= 4 training cycles at every rate
+        w = wav_frames(data, baud, tt)
+        add_case(f"r3/clean/{baud}", w.tolist(), baud,
+                 gen={"kind": "wav", "payload_hex": data.hex(), "baud": baud, "training_time": tt, "total": None})
+        lead = int(rng5.integers(1, 3 * bf)) | 1     # odd: 2-byte-aligned clock index
+        wl = np.concatenate([np.zeros(lead, np.int16), w])
+        add_case(f"r3/lead{lead}/{baud}", wl.tolist(), baud,
+                 gen={"kind": "wav_lead", "payload_hex": data.hex(), "baud": baud, "training_time": tt, "lead": lead})
+        for snr in (9, 4):
+            q = snr_to_scale_q24(snr)
+            noisy = O.add_noise(w, seed=81, stream_idx=baud + snr, scale_q24=q)
+            add_case(f"r3/noise/{baud}/snr{snr}", noisy.tolist(), baud,
+                     gen={"kind": "wav_noise", "payload_hex": data.hex(), "baud": baud, "training_time": tt,
+                          "total": len(w), "seed": 81, "stream_idx": baud + snr, "scale_q24": q, "snr_db": snr})
+        total = 6000 + 10 * bf
+        x = O.add_noise(np.zeros(total, np.int16), seed=4444, stream_idx=baud, scale_q24=1 << 22)
+        add_case(f"r3/garbage/{baud}", x.tolist(), baud,
+                 gen={"kind": "garbage", "total": total, "seed": 4444, "stream_idx": baud, "scale_q24": 1 << 22})
     G["decode_cases"] = cases
 
     # ---- 5b. live gate (Receiver.__listen ref:299-319) replayed over finite captures
