@@ -1010,6 +1010,22 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 #pragma unroll
         for (int piece = 0; piece < SPL; piece++) {
             const int kk = k0 + 64 * piece;
+            if constexpr (BF == 4) {
+                // One sample per quarter.  With the limited samples L0..L3 (biased levels 0 / 0x8000 / 0xFFFF)
+                // mark = (65535 - L0) + L1 + (65535 - L2) + L3 and space = (65535 - L0) + (65535 - L1) + L2 + L3
+                // (ref:80-85, 68-77, 346-347), so mark - space = 2 (L1 - L2): equal levels tie (bit 0, ref:350),
+                // different levels differ by at least 32767, far more than the truncation of the two means can
+                // hide -- the decision int(mark / 4) < int(space / 4) IS L1 < L2 (exhaustive check:
+                // tests/test_kernel_math.py).  The two quotients themselves are only needed for the margins.
+                const uint32_t l0 = limit_pair_biased(x[NO * piece]), l1 = limit_pair_biased(x[NO * piece + 1]);
+                B[piece] = __ballot((l0 >> 16) < (l1 & 0xFFFFu));              // ref:348-351
+                if (margins && kk + lane < mlim) {
+                    const uint32_t mk = __builtin_amdgcn_sad_u16(l1, 0x0000FFFFu, __builtin_amdgcn_sad_u16(l0, 0x0000FFFFu, 0u));
+                    const uint32_t sp = __builtin_amdgcn_sad_u16(l1, 0x00000000u, __builtin_amdgcn_sad_u16(l0, 0xFFFFFFFFu, 0u));
+                    margins[kk + lane] = (int32_t)(sp / 4u) - (int32_t)(mk / 4u);
+                }
+                continue;
+            }
             uint32_t mark = 0, space = 0;
             if constexpr (BF % 8 == 0) {
                 // quarters are whole dwords: SAD against "hi" per quarter gives both correlators
@@ -1224,14 +1240,14 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
 // length), so a lane runs NB dwords against its constant template (ONE v_sad_u16 against "hi" per dword
 // serves both correlators: SAD against lo = 65535 * n - SAD against hi) and two tail slots with per-lane
 // template dwords (the second one masked off for lanes with NB + 1 dwords).  All 64 lanes work for every
-// bit_frames; rounds are 3.8 - 7.5 KiB of whole symbols with the watermark refill, linear reads into the
+// bit_frames; rounds are 3.8 - 8 KiB of whole symbols with the watermark refill, linear reads into the
 // mirror behind the ring, 2-byte-aligned dword reads (a clock index may be odd).
 template <int BF>
 struct GpGeom {
     static constexpr int Q = BF / 4, D = BF / 2;
     static constexpr int pick_lps() {
         int l = 4;
-        while (l < 64 && (64 / l) * 2 * BF > 7680) l *= 2;
+        while (l < 64 && (64 / l) * 2 * BF > 8192) l *= 2;   // (7680: bit_frames 500 / 1000 / 2000 take half the pieces, 3 - 7 % slower at 4096 streams)
         return l;
     }
     static constexpr int LPS = pick_lps();                        // lanes per symbol
@@ -1321,8 +1337,18 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
         const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));
         typedef uint32_t u32_al2 __attribute__((aligned(2)));
         uint32_t x[NB + 2];
+        // A piece starts on a dword of the stream when the clock index is even: typed as 4-byte aligned, the
+        // reads pair up as ds_read2_b32, which needs no more than that.  (Typed as 2-byte aligned the compiler
+        // merges them into 8- and 16-byte reads, which the hardware executes several times slower at such
+        // addresses -- 5 us per 4096 streams at 240 / 160 / 120 / 80 baud.)  An odd clock index takes the
+        // 2-byte-aligned form.
+        if ((byte0 & 2) == 0) {
 #pragma unroll
-        for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const u32_al2*>(src + 4 * d);
+            for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const u32_al2*>(src + 4 * d);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
 
@@ -1561,10 +1587,16 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
         const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));   // linear from here: the mirror covers a piece
         uint32_t h = 0, amp = 0;
         int d = 0;
+        const bool even = (byte0 & 2) == 0;                       // pieces start on a dword: see gp_rounds
         for (; d + 4 <= nb; d += 4) {                             // four reads in flight per step
             uint32_t x[4];
+            if (even) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const u32_a2*>(src + 4 * (d + u));
+                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const uint32_t*>(src + 4 * (d + u));
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const u32_a2*>(src + 4 * (d + u));
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[u]), 0xFFFFFFFFu, h);      // ref:344, 346-347

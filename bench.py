@@ -20,6 +20,7 @@ and so do the three built "next" rows of SURVEY 8(f), each with its own roofline
   f1_modulate    on-device modulator (write-bound, config5 shape)
   f2_gate        live-gate replay (read-bound) over 4096 and 65536 captures
   f3_wav_ingest  4096 .wav files -> device layout (PCIe-bound: against a pinned hipMemcpy of the bytes)
+plus `rates_4096`: 4096 x 1 s at each of the 36 rates a Receiver can be built for (12000 ... 24 baud).
 At N > 1 the config2 shard is carried as a sub-record (worst case for the per-collective cost).
 
 Timing: a timed region is EXACTLY K steps between two fences (barrier + synchronize on both sides);
@@ -69,6 +70,9 @@ WORKLOADS = {
 }
 HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
 NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest")   # SURVEY 8(f) rows carried as sub-records at N = 1
+RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
+# 48000 / baud must divide 48000 and be a multiple of 4: 12000 ... 24 baud
+ALL_RATES = tuple(48000 // bf for bf in range(4, 2048, 4) if 48000 % bf == 0)
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
 STREAM_LEN = 48000
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -98,14 +102,15 @@ def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
     elif workload or streams:
         names = []
     else:
-        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) if world == 1 else ["config2"]
+        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) + [RATES_ROW] if world == 1 else ["config2"]
+    riders = NEXT_ROWS + (RATES_ROW,)
     for x in [main] + names:
-        if x not in WORKLOADS and x not in NEXT_ROWS:
+        if x not in WORKLOADS and x not in riders:
             raise SystemExit(f"unknown workload {x}")
-    if main in NEXT_ROWS:
-        raise SystemExit("the next rows (f1/f2/f3) are sub-records, not headline workloads")
+    if main in riders:
+        raise SystemExit("f1 / f2 / f3 / rates_4096 are sub-records, not headline workloads")
     return {"main": main, "subs": [x for x in names if x in WORKLOADS and x != main],
-            "next": [x for x in names if x in NEXT_ROWS]}
+            "next": [x for x in names if x in riders]}
 
 
 def config_block(name: str, n_local: int, world: int, backend: str = "nccl", share_gpu0: bool = False) -> dict:
@@ -222,11 +227,13 @@ class Ctx:
 class Shard:
     """This rank's contiguous range of one workload's streams, synthesised on the device."""
 
-    def __init__(self, ctx: Ctx, name: str, n_local: int, snr_db=None, copies: int = 0):
+    def __init__(self, ctx: Ctx, name: str, n_local: int, snr_db=None, copies: int = 0, bauds=None, desc=None):
         from afskmodem_amd import batch, synth
         from afskmodem_amd import dist as adist
         torch = ctx.torch
-        _, bauds, wl_snr, desc = WORKLOADS[name]
+        _, wl_bauds, wl_snr, wl_desc = WORKLOADS[name]
+        bauds = tuple(bauds) if bauds is not None else wl_bauds
+        desc = desc or wl_desc
         self.ctx, self.name, self.desc, self.bauds = ctx, name, desc, bauds
         self.snr_db = wl_snr if snr_db is None else snr_db
         self.n_local = n_local
@@ -807,6 +814,39 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
+def measure_rates(ctx: Ctx, steps: int = 60, n_streams: int = 4096, check_streams: int = 64) -> dict:
+    """4096 x 1 s clean streams at EVERY rate a Receiver can be built for (bit_frames must divide 48000 and
+    be a multiple of 4: 36 values, 12000 ... 24 baud), each through its own uniform kernel: time per launch,
+    fraction of the HBM peak in algorithmic bytes, round trip to the modulated payloads and the CPU oracle
+    on a sample.  (Below ~100 baud a 1 s stream holds 0 - 2 payload bytes: training, terminator and tail.)"""
+    rows = {}
+    cores = os.cpu_count() or 1
+    for baud in ALL_RATES:
+        sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
+        rec, aux = measure(ctx, sh, steps, 10, 20.0, 0, 0.0)
+        row = {"bit_frames": 48000 // baud, "payload_bytes": int(sh.plen_h[0]), "entry": rec["entry"],
+               "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
+               "kernel_ms_median": rec["roofline"]["kernel_ms_median"], "frac": rec["roofline"]["frac"],
+               "frac_at_median": rec["roofline"]["frac_at_median"],
+               "algorithmic_bytes_per_launch": rec["roofline"]["algorithmic_bytes_per_launch"],
+               "full_buffer_gbs": rec["roofline"]["full_buffer_gbs"],
+               "roundtrip_match_rate": rec["roundtrip_match_rate"],
+               "all_timed_steps_identical": rec["all_timed_steps_identical"]}
+        if not ctx.args.no_cpu_baseline:
+            row["match_rate"], _, _ = oracle_match(sh, aux["res"], aux["got_payloads"], sh.inputs[0],
+                                                   min(check_streams, n_streams), cores)
+        rows[str(baud)] = row
+        del sh, aux
+        ctx.torch.cuda.empty_cache()
+    fr = [r["frac"] for r in rows.values()]
+    return {"row": f"{n_streams} x 1 s clean streams at each of the {len(rows)} rates a Receiver can be built for "
+                   "(afsk_demod_batch_uniform: one kernel per bit_frames)",
+            "steps": steps, "min_frac": min(fr), "max_frac": max(fr),
+            "rates_below_0.60": [b for b, r in rows.items() if r["frac"] < 0.60],
+            "all_round_trips_exact": all(r["roundtrip_match_rate"] == 1.0 for r in rows.values()),
+            "by_baud": rows}
+
+
 def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s: float = 10.0, idx=None, label=""):
     """The CPU oracle (C port of the reference hot path) timed on this box's host cores on a bounded
     sample of the shard (the first ns streams, or the streams listed in idx), checked against the GPU's
@@ -971,6 +1011,8 @@ def run_rank(args) -> None:
         torch.cuda.empty_cache()
     if world == 1 and "f3_wav_ingest" in next_rows:
         subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
+    if world == 1 and RATES_ROW in next_rows:
+        subs[RATES_ROW] = measure_rates(ctx)
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
@@ -997,7 +1039,7 @@ def main() -> None:
     ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
                     help="headline workload (default: config5 at every N); "
                          "giving one explicitly drops the sub-records unless --sub lists them")
-    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest ('' = none)")
+    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest,rates_4096 ('' = none)")
     ap.add_argument("--min-region-ms", type=float, default=50.0,
                     help="repeat the K-step timed region until the regions add up to this (0 = exactly one region)")
     ap.add_argument("--entry", default="auto", choices=["auto", "mixed"],

@@ -71,7 +71,8 @@ def test_headline_workload_is_the_same_at_every_n():
     assert blocks[1]["workload"] == blocks[2]["workload"] == blocks[8]["workload"]
     assert blocks[8]["streams_total"] == 524288
     one, two = bench.plan(1), bench.plan(2)
-    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS)
+    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS) + [bench.RATES_ROW]
+    assert len(bench.ALL_RATES) == 36 and set((300, 1200, 2400, 100, 160, 96, 24, 12000)) <= set(bench.ALL_RATES)
     assert two["subs"] == ["config2"] and two["next"] == []
     # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline
     assert bench.plan(1, "config2") == {"main": "config2", "subs": [], "next": []}

@@ -168,7 +168,7 @@ def gp_geom(bf):
     """GpGeom<BF> restated: lanes per symbol, and per lane (quarter k, first dword, dword count)."""
     q = bf // 4
     lps = 4
-    while lps < 64 and (64 // lps) * 2 * bf > 7680:
+    while lps < 64 and (64 // lps) * 2 * bf > 8192:
         lps *= 2
     lpq = lps // 4
     qs = lambda k: (k * q + 1) // 2  # noqa: E731
@@ -185,10 +185,10 @@ def gp_geom(bf):
 def test_general_piece_map_covers_every_symbol_once(bf):
     """gp_rounds: the LPS lanes of a symbol own disjoint runs of its bf/2 dwords, every lane NB + 1 or
     NB + 2 of them, a run lies inside ONE quarter except that its last dword may straddle into the next
-    (odd quarter length), rounds are whole symbols of at most 7.5 KiB, a piece fits the 256-byte mirror."""
+    (odd quarter length), rounds are whole symbols of at most 8 KiB, a piece fits the 256-byte mirror."""
     lps, lanes = gp_geom(bf)
     q, d = bf // 4, bf // 2
-    assert 64 % lps == 0 and (64 // lps) * 2 * bf <= 7680
+    assert 64 % lps == 0 and (64 // lps) * 2 * bf <= 8192
     cover = np.zeros(d, int)
     sizes = {n for _, _, n in lanes}
     nb = min(sizes) - 1
@@ -252,3 +252,16 @@ def test_sliding_correlation_identity_long_and_odd_quarters(bf):
         mm = -(-2 ** 36 // n)
         m = np.concatenate([rng.integers(0, 65535 * n + 1, 20000), [0, 65535 * n, n - 1, n, 65535 * n - 1]]).astype(object)
         assert all(((int(v) * mm) >> 36) == int(v) // n for v in m)
+
+
+def test_bit_frames_4_decision_is_a_level_comparison():
+    """multi_rounds<4> (12000 baud): with one sample per quarter the decision int(mark / 4) < int(space / 4)
+    of ref:346-351 equals L1 < L2 on the limited samples -- exhaustive over the 3^4 level combinations."""
+    import itertools
+    levels = (-32768, 0, 32767)                                  # limiter outputs (ref:287-296)
+    mark_t = (32767, -32768, 32767, -32768)                      # ref:80-85 at bit_frames 4
+    space_t = (32767, 32767, -32768, -32768)                     # ref:68-77
+    for s in itertools.product(levels, repeat=4):
+        md = int(sum(abs(t - v) for t, v in zip(mark_t, s)) / 4)
+        sd = int(sum(abs(t - v) for t, v in zip(space_t, s)) / 4)
+        assert (md < sd) == (s[1] < s[2]), s
