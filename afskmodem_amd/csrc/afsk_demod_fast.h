@@ -1269,8 +1269,20 @@ struct GpGeom {
         return m;
     }
     static constexpr int NB = min_piece() - 1;                    // dwords every lane runs against its constant template
+    // largest power of two (bytes, at most 16) that divides the offset of every lane piece inside a round
+    static constexpr int piece_align() {
+        int a = 16;
+        while (a > 4 && (2 * BF) % a != 0) a /= 2;
+        for (int k = 0; k < 4; k++)
+            for (int j = 0; j < LPQ; j++) {
+                const int d0 = qs(k) + (j * (qs(k + 1) - qs(k))) / LPQ;
+                while (a > 4 && (4 * d0) % a != 0) a /= 2;
+            }
+        return a;
+    }
+    static constexpr int PALIGN = piece_align();
     static constexpr bool valid = BF % 4 == 0 && BF >= 64 && 2 * BF < kSync && NB >= 1 && max_piece() <= NB + 2 &&
-                                  4 * (NB + 2) + 4 <= kMirrorBytes && RBYTES + 4 + 1023 < kRingBytes;
+                                  4 * (NB + 3) <= kMirrorBytes && RBYTES + 4 + 1023 < kRingBytes;
 };
 
 // sum over the LPS lanes of an aligned group; the result is valid in the LAST lane of the group (for LPS
@@ -1334,20 +1346,41 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
                     *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
             wave_lds_sync();
         }
-        const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));
-        typedef uint32_t u32_al2 __attribute__((aligned(2)));
-        uint32_t x[NB + 2];
-        // A piece starts on a dword of the stream when the clock index is even: typed as 4-byte aligned, the
-        // reads pair up as ds_read2_b32, which needs no more than that.  (Typed as 2-byte aligned the compiler
-        // merges them into 8- and 16-byte reads, which the hardware executes several times slower at such
-        // addresses -- 5 us per 4096 streams at 240 / 160 / 120 / 80 baud.)  An odd clock index takes the
-        // 2-byte-aligned form.
-        if ((byte0 & 2) == 0) {
+        // The piece is read from the dword-aligned address at or below its first byte (an odd clock index puts
+        // it 2 bytes into a dword) and shifted in registers.  The reads are typed by what is KNOWN about that
+        // address, because the compiler merges adjacent dword reads into 8- and 16-byte reads and the hardware
+        // executes those several times slower at addresses that are not that aligned (5 us per 4096 streams at
+        // 240 / 160 / 120 / 80 baud, 15 % at 32768 x 160 baud): geometries whose pieces all start on 16- (8-)
+        // byte multiples of the round read 16 (8) bytes at a time when the clock index allows it (bit_frames
+        // 192, 384, 640 ...: 6 % faster than dword pairs); everything else reads dword pairs (ds_read2_b32
+        // needs 4-byte alignment only).
+        const int sh = byte0 & 2;                                     // wave-uniform: 0, or 2 for an odd clock index
+        const uint8_t* src = fr.ring + (((rb + piece_byte) & (kRingBytes - 1)) - sh);
+        constexpr int PALIGN = G::PALIGN;
+        constexpr int NW = NB + 3;                                    // one dword more for the shifted form
+        uint32_t W[NW];
+        if (PALIGN >= 8 && (byte0 & (PALIGN - 1)) == 0) {
+            constexpr int VW = PALIGN / 4;                            // dwords per read
+            typedef uint32_t uvec __attribute__((ext_vector_type(VW), aligned(PALIGN)));
 #pragma unroll
-            for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+            for (int v = 0; v < NW / VW; v++) {
+                const uvec t = *reinterpret_cast<const uvec*>(src + PALIGN * v);
+#pragma unroll
+                for (int u = 0; u < VW; u++) W[VW * v + u] = t[u];
+            }
+#pragma unroll
+            for (int d = (NW / VW) * VW; d < NW; d++) W[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
         } else {
 #pragma unroll
-            for (int d = 0; d < NB + 2; d++) x[d] = *reinterpret_cast<const u32_al2*>(src + 4 * d);
+            for (int d = 0; d < NW; d++) W[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+        }
+        uint32_t x[NB + 2];
+        if (sh == 0) {
+#pragma unroll
+            for (int d = 0; d < NB + 2; d++) x[d] = W[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB + 2; d++) x[d] = __builtin_amdgcn_alignbyte(W[d + 1], W[d], 2);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
@@ -1449,7 +1482,6 @@ __device__ __forceinline__ void rxd_pass_rt(RxDeferred& d, uint64_t bmask, int n
 // 2-byte-aligned ds_read_b128 execute on gfx950, but several times slower.
 __device__ __forceinline__ int recover_clock_index_rt(FastRing& fr, int bf) {
     constexpr int GC = 24, STEP = 64 * GC;
-    typedef u32x4 u32x4_al4 __attribute__((aligned(4)));
     const int lane = fr.lane;
     const int N = 2 * bf, q = bf >> 2, h = bf >> 1, NOFF = kSync - N;
     fr.template wait_fixed<kRingChunks - 8>(7);                 // chunks 0..7 (samples 0..4095) have landed
@@ -1487,13 +1519,9 @@ __device__ __forceinline__ int recover_clock_index_rt(FastRing& fr, int bf) {
         for (int e = 0; e < 7; e++) {
             const uint8_t* p = src + 2 * (lag[e] & ~1);
             const uint32_t sh = (lag[e] & 1) ? 2u : 0u;           // wave-uniform
-            uint32_t W[GC / 2 + 1];
-#pragma unroll
-            for (int j = 0; j < GC / 8; j++) {
-                const u32x4 t4 = *reinterpret_cast<const u32x4_al4*>(p + 16 * j);
-                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
-            }
-            W[GC / 2] = *reinterpret_cast<const uint32_t*>(p + 2 * GC);
+            uint32_t W[GC / 2 + 1];                               // dword reads (they pair up as ds_read2_b32): a 16-byte
+#pragma unroll                                                    // read at a 4-byte-aligned address is a slow one
+            for (int j = 0; j <= GC / 2; j++) W[j] = *reinterpret_cast<const uint32_t*>(p + 4 * j);
 #pragma unroll
             for (int j = 0; j < GC / 2; j++) R[e][j] = __builtin_amdgcn_alignbyte(W[j + 1], W[j], sh);
         }
@@ -1584,32 +1612,36 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
                     *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
             wave_lds_sync();
         }
-        const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));   // linear from here: the mirror covers a piece
+        // linear from the dword-aligned address at or below the piece (an odd clock index puts it 2 bytes into
+        // a dword; the mirror covers a piece): dword reads the compiler may pair up but never merges into reads
+        // wider than their real alignment (gp_rounds has the story), shifted by 0 or 2 bytes in registers
+        const uint32_t sh = (uint32_t)(byte0 & 2);                // wave-uniform
+        const uint8_t* src = fr.ring + (((rb + piece_byte) & (kRingBytes - 1)) - (int)sh);
         uint32_t h = 0, amp = 0;
         int d = 0;
-        const bool even = (byte0 & 2) == 0;                       // pieces start on a dword: see gp_rounds
-        for (; d + 4 <= nb; d += 4) {                             // four reads in flight per step
-            uint32_t x[4];
-            if (even) {
+        for (; d + 4 <= nb; d += 4) {                             // five reads in flight per step
+            uint32_t W[5];
 #pragma unroll
-                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const uint32_t*>(src + 4 * (d + u));
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const u32_a2*>(src + 4 * (d + u));
-            }
+            for (int u = 0; u < 5; u++) W[u] = *reinterpret_cast<const uint32_t*>(src + 4 * (d + u));
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[u]), 0xFFFFFFFFu, h);      // ref:344, 346-347
-                amp = __builtin_amdgcn_sad_u16(x[u] ^ kBias, kBias, amp);                   // ref:94-98
+                const uint32_t x = __builtin_amdgcn_alignbyte(W[u + 1], W[u], sh);
+                h = __builtin_amdgcn_sad_u16(limit_pair_biased(x), 0xFFFFFFFFu, h);         // ref:344, 346-347
+                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);                      // ref:94-98
             }
         }
+        uint32_t prev = *reinterpret_cast<const uint32_t*>(src + 4 * d);
         for (; d < nb; d++) {
-            const uint32_t x = *reinterpret_cast<const u32_a2*>(src + 4 * d);
+            const uint32_t next = *reinterpret_cast<const uint32_t*>(src + 4 * d + 4);
+            const uint32_t x = __builtin_amdgcn_alignbyte(next, prev, sh);
+            prev = next;
             h = __builtin_amdgcn_sad_u16(limit_pair_biased(x), 0xFFFFFFFFu, h);
             amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);
         }
-        const uint32_t xa = *reinterpret_cast<const u32_a2*>(src + 4 * nb);
-        const uint32_t xb = *reinterpret_cast<const u32_a2*>(src + 4 * nb + 4);
+        const uint32_t wa = *reinterpret_cast<const uint32_t*>(src + 4 * nb + 4);
+        const uint32_t wb = *reinterpret_cast<const uint32_t*>(src + 4 * nb + 8);
+        const uint32_t xa = __builtin_amdgcn_alignbyte(wa, prev, sh);
+        const uint32_t xb = __builtin_amdgcn_alignbyte(wb, wa, sh);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the round's reads have returned: refill
         fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + rbytes) >> 10) + kRingChunks);
         const uint32_t la = limit_pair_biased(xa), lb = limit_pair_biased(xb);
