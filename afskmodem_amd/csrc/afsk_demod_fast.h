@@ -1017,13 +1017,11 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
                 // different levels differ by at least 32767, far more than the truncation of the two means can
                 // hide -- the decision int(mark / 4) < int(space / 4) IS L1 < L2 (exhaustive check:
                 // tests/test_kernel_math.py).  The two quotients themselves are only needed for the margins.
-                const uint32_t l0 = limit_pair_biased(x[NO * piece]), l1 = limit_pair_biased(x[NO * piece + 1]);
-                B[piece] = __ballot((l0 >> 16) < (l1 & 0xFFFFu));              // ref:348-351
-                if (margins && kk + lane < mlim) {
-                    const uint32_t mk = __builtin_amdgcn_sad_u16(l1, 0x0000FFFFu, __builtin_amdgcn_sad_u16(l0, 0x0000FFFFu, 0u));
-                    const uint32_t sp = __builtin_amdgcn_sad_u16(l1, 0x00000000u, __builtin_amdgcn_sad_u16(l0, 0xFFFFFFFFu, 0u));
-                    margins[kk + lane] = (int32_t)(sp / 4u) - (int32_t)(mk / 4u);
-                }
+                // Only samples 1 and 2 decide: one dword holding both goes through ONE limiter.  (The margins,
+                // which need all four samples, are formed after the loop.)
+                const uint32_t y = __builtin_amdgcn_alignbit(x[NO * piece + 1], x[NO * piece], 16);   // (sample 1, sample 2)
+                const uint32_t l12 = limit_pair_biased(y);
+                B[piece] = __ballot((l12 & 0xFFFFu) < (l12 >> 16));            // ref:348-351
                 continue;
             }
             uint32_t mark = 0, space = 0;
@@ -1049,6 +1047,18 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
             if (margins && kk + lane < mlim) margins[kk + lane] = (int32_t)sd - (int32_t)md;
             B[piece] = __ballot(md < sd);                                      // ref:348-351
+        }
+        if constexpr (BF == 4) {
+            if (margins) {                                                     // soft output: the two quotients (ref:346-349)
+#pragma unroll
+                for (int piece = 0; piece < SPL; piece++) {
+                    const int kk = k0 + 64 * piece;
+                    const uint32_t l0 = limit_pair_biased(x[NO * piece]), l1 = limit_pair_biased(x[NO * piece + 1]);
+                    const uint32_t mk = __builtin_amdgcn_sad_u16(l1, 0x0000FFFFu, __builtin_amdgcn_sad_u16(l0, 0x0000FFFFu, 0u));
+                    const uint32_t sp = __builtin_amdgcn_sad_u16(l1, 0x00000000u, __builtin_amdgcn_sad_u16(l0, 0xFFFFFFFFu, 0u));
+                    if (kk + lane < mlim) margins[kk + lane] = (int32_t)(sp / 4u) - (int32_t)(mk / 4u);
+                }
+            }
         }
         auto amp_word = [&](int piece) {                                       // ref:94-98, ref:375
             uint32_t amp = 0;
