@@ -814,7 +814,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def measure_rates(ctx: Ctx, steps: int = 60, n_streams: int = 4096, check_streams: int = 64) -> dict:
+def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_streams: int = 64) -> dict:
     """4096 x 1 s clean streams at EVERY rate a Receiver can be built for (bit_frames must divide 48000 and
     be a multiple of 4: 36 values, 12000 ... 24 baud), each through its own uniform kernel: time per launch,
     fraction of the HBM peak in algorithmic bytes, round trip to the modulated payloads and the CPU oracle
@@ -823,7 +823,7 @@ def measure_rates(ctx: Ctx, steps: int = 60, n_streams: int = 4096, check_stream
     cores = os.cpu_count() or 1
     for baud in ALL_RATES:
         sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
-        rec, aux = measure(ctx, sh, steps, 10, 20.0, 0, 0.0)
+        rec, aux = measure(ctx, sh, steps, 10, 50.0, 0, 0.0)          # 50 ms pre-roll: every rate starts from settled clocks
         row = {"bit_frames": 48000 // baud, "payload_bytes": int(sh.plen_h[0]), "entry": rec["entry"],
                "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
                "kernel_ms_median": rec["roofline"]["kernel_ms_median"], "frac": rec["roofline"]["frac"],
