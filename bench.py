@@ -312,13 +312,14 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     n_local, stride, flat_sz = sh.n_local, sh.stride, sh.flat_sz
     world, rank = ctx.world, ctx.rank
 
-    # Each collective costs the compute stream ~40 us (cross-stream events around it),
-    # so a group should cover a few ms of kernels: 64 steps of config #2, 3-4 of the 6.29 GB ones.
+    # Each collective costs the compute stream ~40 us (cross-stream events around it; DESIGN 6: +2.9 % per
+    # step of the config #5 shard at one collective per 3 steps), so a group covers ~16 ms of kernels: 64
+    # steps of config #2, 15 of the 6.29 GB ones (then +0.3 %).
     est_step_s = 2.0 * n_local * STREAM_LEN / 6.0e12
     if gather_every > 0:
         G = gather_every
     else:
-        G = max(1, min(64, int(4e-3 / est_step_s)))
+        G = max(1, min(64, int(16e-3 / est_step_s)))
     if comm is None:
         G = 1
     # one output slot per step (so any step can be checked afterwards), at most 256, whole groups
