@@ -4,7 +4,8 @@ Streams are independent (nothing in afskmodem.py:354-381 couples two streams),
 so the data path has no collective: rank r demodulates the contiguous range
 ``shard_range(n, r, world)`` with its own kernel launches.  The only exchange is
 an optional gather of the decoded bytes + five int32 per stream, done as ONE
-fixed-stride all-gather (RCCL over xGMI with backend "nccl"; gloo on CPU tests).
+fixed-stride collective -- to one rank (``gather_flat_to_root``) or to all (``gather_flat``) --
+over RCCL / xGMI with backend "nccl" (gloo on CPU tests).
 """
 from __future__ import annotations
 
@@ -50,6 +51,28 @@ def gather_flat(res, n_total: int, group=None, out=None):
     if out is None:
         out = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)
+    return split_gathered(out, world, n_local, stride)
+
+
+def gather_flat_to_root(res, n_total: int, dst: int = 0, group=None, out=None):
+    """Equal shards, records wanted on ONE rank: every rank sends ``res.flat`` to rank ``dst``
+    (``torch.distributed.gather``: over RCCL one direct transfer per rank into dst's xGMI links -- never a
+    ring -- and 1/world of the all-gather's traffic).  Returns the list of per-rank DemodResult views on
+    ``dst`` and None on the other ranks.  ``out``: optional preallocated uint8 [world * flat] on dst."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local, stride = int(res.bytes.shape[0]), int(res.bytes.shape[1])
+    assert n_total == n_local * world, "gather_flat_to_root needs equal shards"
+    flat = res.flat
+    if rank != dst:
+        dist.gather(flat, None, dst=dst, group=group)
+        return None
+    if out is None:
+        out = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
+    per = flat.numel()
+    dist.gather(flat, [out[r * per: (r + 1) * per] for r in range(world)], dst=dst, group=group)
     return split_gathered(out, world, n_local, stride)
 
 

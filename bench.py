@@ -208,6 +208,26 @@ class Ctx:
         self.dist.all_gather_into_tensor(h_out, inp.cpu())
         out.copy_(h_out)
 
+    def collect(self, out, inp) -> None:
+        """The exchange of the decoded records.  --gather-mode root (default): every rank's buffer goes to
+        rank 0 (north_star: RCCL 'only to gather decoded byte buffers'; on the point-to-point xGMI fabric
+        that is one direct transfer per rank into rank 0's seven ingress links, never a ring);
+        --gather-mode all: all_gather_into_tensor, every rank ends up with every rank's records.
+        `out` ([world * n] on every rank; only rank 0's is filled in root mode), `inp` [n]."""
+        if self.args.gather_mode == "all":
+            self.all_gather(out, inp)
+            return
+        n = inp.numel()
+        if self.backend == "nccl":
+            parts = [out[r * n: (r + 1) * n] for r in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(inp, parts, dst=0)
+            return
+        h_in = inp.cpu()
+        h_parts = [self.torch.empty_like(h_in) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(h_in, h_parts, dst=0)
+        if self.rank == 0:
+            out.copy_(self.torch.cat(h_parts))
+
     def all_reduce(self, t, op=None) -> None:
         kw = {} if op is None else {"op": op}
         if self.backend == "nccl":
@@ -312,14 +332,15 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     n_local, stride, flat_sz = sh.n_local, sh.stride, sh.flat_sz
     world, rank = ctx.world, ctx.rank
 
-    # Each collective costs the compute stream ~40 us (cross-stream events around it; DESIGN 6: +2.9 % per
-    # step of the config #5 shard at one collective per 3 steps), so a group covers ~16 ms of kernels: 64
-    # steps of config #2, 15 of the 6.29 GB ones (then +0.3 %).
+    # Each collective costs the compute stream ~40 us (cross-stream events around it), so a group
+    # should cover a few ms of kernels -- but the LAST group's exchange has nothing left to overlap with and
+    # sits inside the timed region, so groups stay small: ~4 ms = 64 steps of config #2, 3 of the 6.29 GB
+    # ones (7.1 MB of records per rank and step there).
     est_step_s = 2.0 * n_local * STREAM_LEN / 6.0e12
     if gather_every > 0:
         G = gather_every
     else:
-        G = max(1, min(64, int(16e-3 / est_step_s)))
+        G = max(1, min(64, int(4e-3 / est_step_s)))
     if comm is None:
         G = 1
     # one output slot per step (so any step can be checked afterwards), at most 256, whole groups
@@ -367,7 +388,7 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
             if state["timing"] and len(gather_timing) < 256:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record(comm)
-            ctx.all_gather(gath_bufs[g & 1], out_all[gr * G * flat_sz: (gr + 1) * G * flat_sz])
+            ctx.collect(gath_bufs[g & 1], out_all[gr * G * flat_sz: (gr + 1) * G * flat_sz])
             if pair is not None:
                 pair[1].record(comm)
                 gather_timing.append(pair)
@@ -529,7 +550,8 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
         ctx.all_gather(sums, own)
         k_last = (steps - 1) % G
         per_rank = []
-        for rr in range(world):
+        have_all = ctx.args.gather_mode == "all"
+        for rr in (range(world) if (have_all or rank == 0) else ()):
             part = gbuf[rr * G * flat_sz: (rr + 1) * G * flat_sz]
             ok_sum = bool((weighted_sum(torch, part) == sums[rr]).item())
             v = batch.views_of_flat(part[k_last * flat_sz: (k_last + 1) * flat_sz], n_local, stride)
@@ -544,13 +566,16 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
                 same = ((v.bytes[:, :width] == exp[:, :width]) | ~m).all(dim=1) & (v.nbytes == pl)
                 ok_pay = bool(same.all().item())
             per_rank.append(ok_sum and ok_pay is not False)
+        # root mode: rank 0 holds and checks every rank's slice (the other ranks contribute a neutral 1);
+        # all mode: every rank checks every slice
         mine = torch.tensor([int(all(per_rank))], dtype=torch.int32, device=ctx.dev)
         ctx.all_reduce(mine, op=dist.ReduceOp.MIN)
         ones = torch.ones(1, dtype=torch.int32, device=ctx.dev)
         ctx.all_reduce(ones, op=dist.ReduceOp.SUM)
         rec["ranks_seen"] = int(ones.item())
+        rec["gather_mode"] = "all_gather_into_tensor (every rank)" if have_all else "gather to rank 0"
         rec["gather_check"] = per_rank                       # rank 0's view: one entry per producer rank
-        rec["gather_check_on_every_rank"] = bool(mine.item())
+        rec["gather_check_on_every_rank"] = bool(mine.item())   # (root mode: rank 0's verdict, agreed by all_reduce)
         rec["gather_every_steps"] = G
         rec["gathers_in_timed_region"] = -(-steps // G)
         if gather_timing:
@@ -958,7 +983,7 @@ def run_rank(args) -> None:
         "host_issue_ms_per_step": rec["host_issue_ms_per_step"],
     }
     out["config"]["bauds"] = list(sh.bauds)       # (--workload custom --bauds ... replaces the table entry)
-    for k in ("ranks_seen", "gather_check", "gather_check_on_every_rank", "gather_every_steps",
+    for k in ("ranks_seen", "gather_mode", "gather_check", "gather_check_on_every_rank", "gather_every_steps",
               "gathers_in_timed_region", "gather_ms"):
         if k in rec:
             out[k] = rec[k]
@@ -1060,6 +1085,8 @@ def main() -> None:
     ap.add_argument("--gather-every", type=int, default=0,
                     help="N > 1: all-gather the decoded records of G steps with one collective; "
                          "0 = as many steps as take about 4 ms (at most 64)")
+    ap.add_argument("--gather-mode", default="root", choices=["root", "all"],
+                    help="root = decoded records are gathered to rank 0 (default); all = all_gather_into_tensor to every rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product); gloo = diagnostic, collectives staged through the host")
     ap.add_argument("--share-gpu0", action="store_true",

@@ -53,6 +53,25 @@ def _worker_flat(rank, world, port, n_total, stride, q):
     dist.destroy_process_group()
 
 
+def _worker_root(rank, world, port, n_total, stride, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = adist.shard_range(n_total, rank, world)
+    parts = adist.gather_flat_to_root(_flat_result(b, e, stride), n_total, dst=1)     # a root that is not rank 0
+    if rank != 1:
+        ok = parts is None
+    else:
+        ok = len(parts) == world
+        for r, part in enumerate(parts):
+            rb, re_ = adist.shard_range(n_total, r, world)
+            want = _fake_result(rb, re_, stride)
+            ok = ok and all(torch.equal(getattr(part, f), getattr(want, f))
+                            for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"))
+    q.put((rank, ok, n_total))
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n_total, stride, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -97,12 +116,12 @@ def test_flat_layout_views():
     assert res.flat[:84].eq(9).all() and res.status.eq(0).all()
 
 
-@pytest.mark.parametrize("n_total,worker", [(64, "pad"), (33, "pad"), (64, "flat")])
+@pytest.mark.parametrize("n_total,worker", [(64, "pad"), (33, "pad"), (64, "flat"), (64, "root")])
 def test_gather_world2_gloo(n_total, worker):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    target = _worker if worker == "pad" else _worker_flat
+    target = {"pad": _worker, "flat": _worker_flat, "root": _worker_root}[worker]
     procs = [ctx.Process(target=target, args=(r, 2, port, n_total, 40, q)) for r in range(2)]
     for p in procs:
         p.start()

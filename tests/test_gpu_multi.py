@@ -86,6 +86,13 @@ def _rank_main(rank, world, port, n_total, q):
 
         ok = int(full.nbytes.shape[0]) == n_total and same(full, wfull)
         if equal:
+            rparts = adist.gather_flat_to_root(res, n_total, dst=world - 1)           # records to ONE rank
+            torch.cuda.synchronize()
+            if rank == world - 1:
+                ok = ok and len(rparts) == world and all(
+                    bool(torch.equal(rparts[r].flat, parts[r].flat)) for r in range(world))
+            else:
+                ok = ok and rparts is None
             wparts = adist.gather_flat(wflat, n_total)
             ok = ok and len(parts) == world
             for r in range(world):
