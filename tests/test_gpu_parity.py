@@ -595,6 +595,55 @@ def test_squelch_thresholds_and_long_stream(torch_cuda):
     assert got.payloads()[0] == data
 
 
+_MAXLEN_ORACLE = {}
+
+
+@pytest.mark.parametrize("bf", [40, 300])
+def test_maximum_stream_length(torch_cuda, entry, bf):
+    """The longest stream the C-ABI accepts (AFSK_MAX_STREAM_LEN = 2^30 - 2^15 samples, 6.2 hours of audio:
+    byte offsets just below 2^31), filled to the end with a Transmitter frame carrying 1.9 MB (1200 baud) /
+    0.26 MB (160 baud) of payload, inside a launch large enough to arm the tail hint (the other streams are
+    empty): hundreds of thousands of ring laps and deferred ECC flushes, the 32-bit position arithmetic at
+    its limit, the probe spacing of the hint at its largest.  Every output equals the CPU oracle's."""
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * 2 ** 30:
+        pytest.skip("needs ~6 GB of free HBM")
+    dev = "cuda:0"
+    L = _native.MAX_STREAM_LEN
+    baud = 48000 // bf
+    ts = synth.ts_cycles_for(baud, 0.5)
+    plen = (L - ts * 2 * bf - 4 * bf - 4800) // (14 * bf)
+    payload = synth.payload_bytes(1234 + bf, 0, 1, plen)
+    n = 6300                                             # >= kHintMinStreams (mixed) and kHintMinStreamsUniform
+    off = np.zeros(n, np.int64)
+    ln = np.zeros(n, np.int32)
+    ln[17] = L                                           # stream 17 is the long one, at sample offset 0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x = torch.zeros(L, dtype=torch.int16, device=dev)
+    batch.modulate_batch(t(payload), t(np.array([plen], np.int32)), t(np.array([bf], np.int32)),
+                         t(np.array([ts], np.int32)), t(off[:1]), t(ln[17:18]), L, x, True)
+    torch.cuda.synchronize()
+    stride = (plen + 8) & ~3
+    if bf not in _MAXLEN_ORACLE:                         # the oracle needs ~10 s per stream: once for both entries
+        w = O.demod_batch(x.cpu().numpy(), off[:1], ln[17:18], np.array([bf], np.int32), 14000, out_stride=stride)
+        _MAXLEN_ORACLE[bf] = w
+    want = _MAXLEN_ORACLE[bf]
+    res = batch.demod_batch(x, t(off), t(ln), np.full(n, bf, np.int32), 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got_nb, got_bits = int(res.nbytes[17].item()), int(res.nbits[17].item())
+    assert (got_nb, got_bits) == (int(want["nbytes"][0]), int(want["nbits"][0])) and got_nb == plen
+    assert int(res.clock_idx[17].item()) == int(want["clock_idx"][0]) == 0
+    assert int(res.term_frame[17].item()) == int(want["term_frame"][0])
+    assert int(res.status[17].item()) == 0
+    row = res.bytes[17, :plen].cpu().numpy()
+    assert np.array_equal(row, want["bytes"][0, :plen]) and np.array_equal(row, payload[0])
+    st = res.status.cpu().numpy()
+    assert (np.delete(st, 17) == _native.ST_TOO_SHORT).all()
+    del x, res
+    torch.cuda.empty_cache()
+
+
 def test_full_size_config2_roundtrip(torch_cuda):
     """BASELINE config #2 at full size (4096 x 1 s, 1200 baud): decoded == modulated payloads
     for every stream (size-independent round-trip property) + the CPU oracle on ALL 4096 streams
