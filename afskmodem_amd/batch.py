@@ -214,10 +214,30 @@ def _as_device_i32(x, n, device):
     return torch.from_numpy(arr).to(device)
 
 
-def _stream_ptr(stream):
+def _stream_ptr(stream, device=None):
+    """hipStream_t of ``stream``, or of torch's current stream ON ``device`` (the device the data lives
+    on, which need not be the process's current device)."""
     torch = _torch()
-    s = stream if stream is not None else torch.cuda.current_stream()
+    s = stream if stream is not None else torch.cuda.current_stream(device)
     return C.c_void_p(s.cuda_stream)
+
+
+def _same_device(dev, **tensors) -> None:
+    """The C-ABI's device entries take raw pointers of ONE device: refuse mixed placements here,
+    where the tensors can still be seen."""
+    for name, t in tensors.items():
+        if t is not None and t.device != dev:
+            raise ValueError(f"{name} is on {t.device}, samples on {dev}: all tensors of a launch must share one device")
+
+
+def _order_after_current(stream, device) -> None:
+    """Helper tensors built inside a call are uploaded on torch's current stream; a launch on another
+    stream must come after that upload."""
+    torch = _torch()
+    if stream is not None:
+        cur = torch.cuda.current_stream(device)
+        if stream.cuda_stream != cur.cuda_stream:
+            stream.wait_stream(cur)
 
 
 def _uniform_bit_frames(bit_frames):
@@ -270,45 +290,58 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         raise TypeError("stream_offset must be int64 and stream_len int32")
     if not (stream_offset.is_cuda and stream_len.is_cuda):
         raise TypeError("stream_offset / stream_len must be CUDA tensors")
+    _same_device(dev, stream_offset=stream_offset, stream_len=stream_len)
+    if not (stream_offset.is_contiguous() and stream_len.is_contiguous()):
+        raise ValueError("stream_offset / stream_len must be contiguous (the kernel reads them as plain arrays)")
     ubf = None if entry == "mixed" else _uniform_bit_frames(bit_frames)
     if entry == "uniform" and ubf is None:
         raise ValueError("entry='uniform' needs ONE bit_frames value (an int or an all-equal host sequence)")
+    fresh = False                      # tensors created (zero-filled / uploaded) inside this call
     if out is None:
         if out_stride is None:
             raise ValueError("pass out= or out_stride=")
         out = alloc_result(n, int(out_stride), dev)
+        fresh = True
     stride = int(out.bytes.shape[1])
     corrected_ptr = margins_ptr = None
     mstride = 0
     if diagnostics:
         if out.corrected is None:
             out.corrected = torch.zeros(n, dtype=torch.int32, device=dev)
+            fresh = True
         if out.margins is None:
             if margin_stride is None:
                 raise ValueError("diagnostics=True needs margin_stride= (symbols per margins row)")
             out.margins = torch.zeros((n, int(margin_stride)), dtype=torch.int32, device=dev)
+            fresh = True
         corrected_ptr, margins_ptr, mstride = out.corrected.data_ptr(), out.margins.data_ptr(), int(out.margins.shape[1])
+    _same_device(dev, out_bytes=out.bytes, out_nbytes=out.nbytes, out_status=out.status)
     lib = _native.lib()
-    if ubf is not None:
-        _native.check(lib.afsk_demod_batch_uniform(
-            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), ubf,
-            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-            out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream)))
-        return out
-    bf = _as_device_i32(bit_frames, n, dev)
-    if diagnostics:
-        _native.check(lib.afsk_demod_batch_ex(
-            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
-            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-            out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream)))
-    else:
-        _native.check(lib.afsk_demod_batch(
-            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
-            threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-            out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-            out.status.data_ptr(), _stream_ptr(stream)))
+    # the device entries launch on the CURRENT HIP device: make that the one the data lives on
+    with torch.cuda.device(dev):
+        if fresh:
+            _order_after_current(stream, dev)
+        if ubf is not None:
+            _native.check(lib.afsk_demod_batch_uniform(
+                samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), ubf,
+                threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+                out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+                out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
+            return out
+        bf = _as_device_i32(bit_frames, n, dev)
+        _order_after_current(stream, dev)
+        if diagnostics:
+            _native.check(lib.afsk_demod_batch_ex(
+                samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
+                threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+                out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+                out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
+        else:
+            _native.check(lib.afsk_demod_batch(
+                samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), bf.data_ptr(),
+                threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+                out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+                out.status.data_ptr(), _stream_ptr(stream, dev)))
     # keep the bit_frames tensor alive until the launch has been enqueued on the stream
     out._bf_keepalive = bf  # type: ignore[attr-defined]
     return out
@@ -349,15 +382,18 @@ def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
         raise TypeError("stream_offset must be int64 and stream_len int32")
     n = int(stream_offset.numel())
     dev = samples.device
+    _same_device(dev, stream_offset=stream_offset, stream_len=stream_len)
     max_blocks = int(max_stream_len) // 2048
     i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)  # noqa: E731
-    res = GateResult(i32(n), i32(n, max(max_bursts, 1)), i32(n, max(max_bursts, 1)), i32(n),
-                     i32(n, max(max_blocks, 1)))
-    _native.check(_native.lib().afsk_gate_batch(
-        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
-        threshold_gt(amp_start_threshold), threshold_lt(amp_end_threshold), n, int(max_bursts),
-        res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
-        res.burst_len.data_ptr(), res.open_end.data_ptr(), _stream_ptr(stream)))
+    with torch.cuda.device(dev):
+        res = GateResult(i32(n), i32(n, max(max_bursts, 1)), i32(n, max(max_bursts, 1)), i32(n),
+                         i32(n, max(max_blocks, 1)))
+        _order_after_current(stream, dev)          # the zero fills above ran on torch's current stream
+        _native.check(_native.lib().afsk_gate_batch(
+            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
+            threshold_gt(amp_start_threshold), threshold_lt(amp_end_threshold), n, int(max_bursts),
+            res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
+            res.burst_len.data_ptr(), res.open_end.data_ptr(), _stream_ptr(stream, dev)))
     return res
 
 
@@ -499,10 +535,14 @@ def modulate_batch(payload, payload_len, bit_frames, ts_cycles, stream_offset, s
                   (stream_len, torch.int32), (samples, torch.int16)):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dt and t.is_contiguous()):
             raise TypeError("modulate_batch wants contiguous CUDA tensors of the documented dtypes")
-    _native.check(_native.lib().afsk_modulate_batch(
-        payload.data_ptr(), int(payload.shape[1]), payload_len.data_ptr(), bit_frames.data_ptr(),
-        ts_cycles.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
-        int(max_stream_len), n, 1 if wav_quirk else 0, samples.data_ptr(), _stream_ptr(stream)))
+    dev = samples.device
+    _same_device(dev, payload=payload, payload_len=payload_len, bit_frames=bit_frames, ts_cycles=ts_cycles,
+                 stream_offset=stream_offset, stream_len=stream_len)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().afsk_modulate_batch(
+            payload.data_ptr(), int(payload.shape[1]), payload_len.data_ptr(), bit_frames.data_ptr(),
+            ts_cycles.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
+            int(max_stream_len), n, 1 if wav_quirk else 0, samples.data_ptr(), _stream_ptr(stream, dev)))
 
 
 def add_noise_batch(samples, stream_offset, stream_len, max_stream_len: int, scale_q24, seed: int,
@@ -511,9 +551,14 @@ def add_noise_batch(samples, stream_offset, stream_len, max_stream_len: int, sca
     torch = _torch()
     _native.require_device()
     n = int(stream_offset.numel())
-    sc = _as_device_i32(scale_q24, n, samples.device)
-    _native.check(_native.lib().afsk_add_noise_batch(
-        samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
-        sc.data_ptr(), n, int(seed) & 0xFFFFFFFF, int(stream_idx_base) & 0xFFFFFFFF,
-        _stream_ptr(stream)))
-    torch.cuda.current_stream().synchronize() if stream is None else stream.synchronize()
+    dev = samples.device
+    _same_device(dev, stream_offset=stream_offset, stream_len=stream_len)
+    with torch.cuda.device(dev):
+        sc = _as_device_i32(scale_q24, n, dev)
+        _order_after_current(stream, dev)
+        _native.check(_native.lib().afsk_add_noise_batch(
+            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
+            sc.data_ptr(), n, int(seed) & 0xFFFFFFFF, int(stream_idx_base) & 0xFFFFFFFF,
+            _stream_ptr(stream, dev)))
+        # `sc` is released on return: the kernel that reads it must have finished
+        (stream if stream is not None else torch.cuda.current_stream(dev)).synchronize()

@@ -113,6 +113,11 @@ def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
             "next": [x for x in names if x in riders]}
 
 
+# --share-gpu0 (diagnostic): the GPU boxes kill a run with more than 6 processes on one device; a test
+# runner that holds the device itself plus 4 ranks stays below that
+SHARE_GPU0_MAX_RANKS = 4
+
+
 def config_block(name: str, n_local: int, world: int, backend: str = "nccl", share_gpu0: bool = False) -> dict:
     """The `config` object of the result line (no GPU needed to build it)."""
     _, bauds, snr, desc = WORKLOADS[name]
@@ -1105,6 +1110,10 @@ def main() -> None:
         have = torch.cuda.device_count()
         if args.share_gpu0 and args.dist_backend != "gloo":
             sys.stderr.write("bench.py: --share-gpu0 needs --dist-backend gloo (RCCL refuses two ranks on one device)\n")
+            raise SystemExit(2)
+        if args.share_gpu0 and args.gpus > SHARE_GPU0_MAX_RANKS:
+            sys.stderr.write(f"bench.py: --share-gpu0 runs at most {SHARE_GPU0_MAX_RANKS} ranks (the GPU boxes allow "
+                             "6 processes per device, and the caller of this diagnostic usually holds the device too)\n")
             raise SystemExit(2)
         if have < (1 if args.share_gpu0 else args.gpus):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible\n")

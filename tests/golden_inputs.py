@@ -43,6 +43,11 @@ def build_input(case: dict) -> np.ndarray:
         x = O.add_noise(x, g["seed"], g["stream_idx"], g["scale_q24"])
     elif kind == "garbage":
         x = O.add_noise(np.zeros(g["total"], np.int16), g["seed"], g["stream_idx"], g["scale_q24"])
+    elif kind == "recipe":
+        x = build_capture(g["recipe"])
+        if g.get("noise"):
+            seed, stream_idx, scale_q24 = g["noise"]
+            x = O.add_noise(x, seed, stream_idx, scale_q24)
     else:
         raise ValueError(kind)
     x = np.ascontiguousarray(x, dtype=np.int16)
@@ -55,7 +60,11 @@ def build_capture(recipe) -> np.ndarray:
     """A long capture from a list of segments (used by the live-gate cases):
     ["zeros", n] | ["noise", n, seed, scale_q24] (oracle integer noise on silence) |
     ["burst", payload_hex, baud, training_time, keep] (wav samples, first `keep` if not None) |
-    ["square", n, amplitude] (+a, -a, +a, ...)."""
+    ["square", n, amplitude] (+a, -a, +a, ...) |
+    ["burst_level", payload_hex, baud, training_time, keep, level] (the burst with +level / -level
+    instead of full scale; silence stays 0) |
+    ["burst_dc", payload_hex, baud, training_time, keep, num, den, dc] (burst * num // den + dc, clipped
+    to int16)."""
     parts = []
     for seg in recipe:
         kind = seg[0]
@@ -68,6 +77,14 @@ def build_capture(recipe) -> np.ndarray:
             parts.append(w if seg[4] is None else w[: seg[4]])
         elif kind == "square":
             parts.append(np.tile(np.array([seg[2], -seg[2]], np.int16), seg[1] // 2))
+        elif kind == "burst_level":
+            w = _wav(seg[1], seg[2], seg[3])
+            w = w if seg[4] is None else w[: seg[4]]
+            parts.append((np.sign(w.astype(np.int32)) * int(seg[5])).astype(np.int16))
+        elif kind == "burst_dc":
+            w = _wav(seg[1], seg[2], seg[3])
+            w = (w if seg[4] is None else w[: seg[4]]).astype(np.int64)
+            parts.append(np.clip(w * int(seg[5]) // int(seg[6]) + int(seg[7]), -32768, 32767).astype(np.int16))
         else:
             raise ValueError(kind)
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.int16)

@@ -268,21 +268,24 @@ def test_unequal_shards_two_ranks_on_one_gpu():
         assert err == "" and ok, (rank, err)
 
 
-def test_bench_eight_rank_rehearsal_full_size_on_one_gpu():
-    """The driver's 8-GPU scaling run, rehearsed on ONE device at FULL SIZE: `python bench.py --gpus 8`
-    with the default 65536 streams x 1 s per rank (8 x 6.29 GB of inputs resident at once) plus the
-    config2 sub-record, reduced steps.  Launcher, 8 ranks, free port, gather_every grouping, per-rank
-    gather_check, ranks_seen 8, ONE JSON line, rc 0.  (Diagnostic gloo backend: RCCL refuses several
-    ranks on one device; throughput is meaningless by construction.)"""
+def test_bench_three_rank_rehearsal_full_size_on_one_gpu():
+    """The driver's multi-GPU scaling run, rehearsed on ONE device at FULL SIZE per rank: `python bench.py
+    --gpus 3` with the default 65536 streams x 1 s per rank (3 x 6.29 GB of inputs resident at once) plus
+    the config2 sub-record, reduced steps.  Launcher, 3 ranks, free port, gather_every grouping, per-rank
+    gather_check, ranks_seen 3, ONE JSON line, rc 0.  (Diagnostic gloo backend: RCCL refuses several
+    ranks on one device; throughput is meaningless by construction.  Three ranks, not eight: the GPU boxes
+    allow 6 processes per device, and this test runner and the launching bench.py process are two of
+    them; the 8-rank line recorded before that limit existed is
+    profiles/r3_bench_n8_diagnostic_gloo_shared_gpu.json.)"""
     import json
     import subprocess
     import sys
     import torch
     free, _ = torch.cuda.mem_get_info()
-    if free < 80 * 2 ** 30:
-        pytest.skip("needs ~60 GB of free HBM")
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~25 GB of free HBM")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dist-backend", "gloo",
                         "--share-gpu0", "--steps", "5", "--warmup", "1", "--preroll-ms", "0", "--min-region-ms", "0",
                         "--sub-steps", "8"],
                        capture_output=True, text=True, timeout=1500)
@@ -290,10 +293,10 @@ def test_bench_eight_rank_rehearsal_full_size_on_one_gpu():
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8
-    assert d["gather_check"] == [True] * 8 and d["gather_check_on_every_rank"] is True
-    assert d["config"]["streams_per_gpu"] == 65536 and d["config"]["streams_total"] == 524288
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3
+    assert d["gather_check"] == [True] * 3 and d["gather_check_on_every_rank"] is True
+    assert d["config"]["streams_per_gpu"] == 65536 and d["config"]["streams_total"] == 3 * 65536
     assert d["config"]["workload"].startswith("configs[4]")
     assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
     sub = d["sub_records"]["config2"]
-    assert sub["ranks_seen"] == 8 and sub["gather_check"] == [True] * 8 and sub["roundtrip_match_rate"] == 1.0
+    assert sub["ranks_seen"] == 3 and sub["gather_check"] == [True] * 3 and sub["roundtrip_match_rate"] == 1.0

@@ -284,8 +284,10 @@ def test_soft_outputs_golden_cases(golden, torch_cuda):
         ln = np.array([len(xs[i]) for i in idx], np.int32)
         off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
         bf = np.array([48000 // cases[i]["baud"] for i in idx], np.int32)
+        stride = max(160, max(cases[i]["nbytes"] for i in idx) + 8)      # multi-second cases: 100 - 900 bytes
+        mstride = max(4000, max(cases[i]["soft"]["n_symbols"] for i in idx) + 8)
         res, corr, marg, nsym = soft_demod(torch_cuda, np.concatenate([xs[i] for i in idx]), off,
-                                           ln, bf, amp_end, 160, 4000)
+                                           ln, bf, amp_end, stride, mstride)
         pl = res.payloads()
         for j, i in enumerate(idx):
             c = cases[i]
@@ -1197,3 +1199,29 @@ def test_launch_is_graph_capture_safe(torch_cuda, entry):
         for f in FIELDS:
             assert np.array_equal(getattr(got, f), getattr(ref_out, f)), f
         assert np.array_equal(got.bytes, ref_out.bytes)
+
+
+def test_side_stream_launch_with_in_call_allocations(torch_cuda, entry):
+    """demod_batch(stream=side) that allocates its result, its soft outputs and (mixed entry) the device
+    copy of a host bit_frames list INSIDE the call: those fills / uploads run on torch's current stream
+    and the launch on `side` must be ordered behind them.  The current stream is kept busy with a long
+    fill so that a missing dependency would let the zero fill land after the kernel's stores.  Calls the
+    real entry (not the per-rate splitter of the `entry` fixture, which scatters on the current stream)."""
+    torch = torch_cuda
+    bauds = (300, 1200, 2400) if entry == "mixed" else (1200,)
+    b = synth_batch(torch, 192, bauds, seed=314)
+    bf_h = b["bf"].cpu().numpy()
+    stride = batch.out_stride_for(48000, 20)
+    want = O.demod_batch(b["samples"].cpu().numpy(), np.arange(192, dtype=np.int64) * 48000,
+                         np.full(192, 48000, np.int32), bf_h, 14000, out_stride=stride)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    busy = torch.empty(1 << 28, dtype=torch.int32, device="cuda:0")
+    for rep in range(3):
+        busy.fill_(rep)                          # ~1 GB of stores ahead of the in-call fills
+        res = REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], [int(v) for v in bf_h], 14000,
+                               out_stride=stride, stream=side, diagnostics=True, margin_stride=48000 // 20,
+                               entry=entry)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert_same(res.cpu(), want, f"side stream rep {rep}")

@@ -428,3 +428,15 @@ def test_native_riff_walk_matches_the_reference_reader(golden, tmp_path):
             f.writeframes(bytes(((i * 37 + 11) ^ (i >> 3)) & 0xFF for i in range(c["nbytes"])))
         o, nb, st = batch.wav_probe([fn])
         assert st[0] == 0 and nb[0] // 2 == c["n_frames_ref"], c["name"]
+
+
+def test_device_entry_argument_checks_need_no_gpu():
+    """batch._same_device refuses tensors of a launch that live on different devices (the C-ABI takes
+    raw pointers of ONE device); checked with a meta tensor so that no GPU is needed."""
+    import torch
+
+    from afskmodem_amd import batch
+    a = torch.zeros(4, dtype=torch.int64)
+    batch._same_device(a.device, stream_offset=a, stream_len=None)
+    with pytest.raises(ValueError, match="share one device"):
+        batch._same_device(a.device, stream_offset=torch.empty(4, device="meta"))
