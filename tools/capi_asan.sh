@@ -1,0 +1,27 @@
+#!/bin/bash
+# CPU-only sanitizer run of the C-ABI's HOST code (afsk_capi.hip: argument checks, the I/O thread pool and its
+# fork handler, the RIFF chunk walk, afsk_file_sizes): afsk_capi.hip is compiled with
+# -fsanitize=address,undefined for the host side only (-fno-gpu-sanitize; GPU ASan is not available on the
+# pool), the kernel launchers are stubbed (they need a device anyway), and the host-only tests run against
+# the result through AFSK_AMD_LIB.  The ingest / upload / host-buffer entries need a GPU and are not covered.
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+W=$(mktemp -d); trap 'rm -rf "$W"' EXIT
+cat > "$W/stubs.hip" <<S
+#include "$ROOT/afskmodem_amd/csrc/afsk_kernels.h"
+namespace afsk {
+hipError_t launch_gate(const GateArgs&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_demod(const DemodArgs&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_demod_uniform(const DemodArgs&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_modulate(ModulateArgs, int32_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_noise(NoiseArgs, int32_t, hipStream_t) { return hipErrorUnknown; }
+}
+S
+F="-std=c++17 -fPIC --offload-arch=${AFSK_ARCH:-gfx950} -Wno-unused-function"
+hipcc -O1 -g $F -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -c -o "$W/capi.o" "$ROOT/afskmodem_amd/csrc/afsk_capi.hip"
+hipcc -O1 $F -c -o "$W/stubs.o" "$W/stubs.hip"
+hipcc -fPIC --offload-arch=${AFSK_ARCH:-gfx950} -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -shared -o "$W/libafsk_amd_asan.so" "$W/capi.o" "$W/stubs.o"
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+cd "$ROOT"
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT AFSK_AMD_LIB="$W/libafsk_amd_asan.so" \
+  python -m pytest tests/test_wav_probe_fuzz.py tests/test_host_api.py -q -k "wav or riff or file_sizes or fork or argument"
