@@ -25,3 +25,26 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
 cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT AFSK_AMD_LIB="$W/libafsk_amd_asan.so" \
   python -m pytest tests/test_wav_probe_fuzz.py tests/test_host_api.py -q -k "wav or riff or file_sizes or fork or argument"
+# ThreadSanitizer pass over the I/O pool: three Python threads call afsk_wav_probe concurrently (jobs serialise on
+# the pool, workers are shared)
+hipcc -O1 -g $F -fsanitize=thread -fno-gpu-sanitize -c -o "$W/capi_t.o" "$ROOT/afskmodem_amd/csrc/afsk_capi.hip" 2>/dev/null
+hipcc -fPIC --offload-arch=${AFSK_ARCH:-gfx950} -fsanitize=thread -shared-libsan -shared -o "$W/libafsk_amd_tsan.so" "$W/capi_t.o" "$W/stubs.o"
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)
+TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD=$RT AFSK_AMD_LIB="$W/libafsk_amd_tsan.so" python - <<'PY'
+import sys, tempfile, threading, wave
+sys.path.insert(0, ".")
+from afskmodem_amd import batch
+d = tempfile.mkdtemp()
+names = []
+for i in range(600):
+    fn = f"{d}/a{i}.wav"
+    with wave.open(fn, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(48000); f.writeframes(bytes(200 + i))
+    names.append(fn)
+def work(k):
+    for _ in range(20):
+        assert (batch.wav_probe(names[k::3])[2] == 0).all()
+ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("tsan pass ok (any report would have ended the process with code 66)")
+PY
