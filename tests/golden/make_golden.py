@@ -62,6 +62,7 @@ def import_reference():
     stub.PyAudio = _PA
     sys.modules["pyaudio"] = stub
     sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True          # /root/reference is read-only for us: no __pycache__ there
     import afskmodem as ref  # type: ignore
     return ref
 

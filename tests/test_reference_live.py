@@ -43,9 +43,12 @@ def ref():
     stub.Stream, stub.PyAudio = _Stream, _PA
     sys.modules["pyaudio"] = stub
     sys.path.insert(0, os.path.dirname(REF_FILE))
+    no_bytecode = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True          # /root/reference is read-only for us: no __pycache__ there
     try:
         import afskmodem as mod  # type: ignore
     finally:
+        sys.dont_write_bytecode = no_bytecode
         sys.path.remove(os.path.dirname(REF_FILE))
     mod.LOG_LEVEL = 5
     yield mod
