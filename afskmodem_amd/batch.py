@@ -397,10 +397,18 @@ def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
     return res
 
 
-def upload_streams(arrays, device="cuda:0"):
-    """Host int16 arrays (ragged) -> (samples, stream_offset, stream_len, max_len) on the device,
-    stream-major and back to back (the layout every kernel expects)."""
+def _default_device(device):
+    """None -> the process's CURRENT HIP device (one process per GPU sets it once), not cuda:0."""
     torch = _torch()
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def upload_streams(arrays, device=None):
+    """Host int16 arrays (ragged) -> (samples, stream_offset, stream_len, max_len) on the device
+    (default: the current one), stream-major and back to back (the layout every kernel expects)."""
+    torch = _torch()
+    _native.require_device()
+    device = _default_device(device)
     lens = np.array([len(a) for a in arrays], dtype=np.int32)
     offs = np.zeros(len(arrays), dtype=np.int64)
     if len(arrays) > 1:
@@ -451,7 +459,7 @@ def wav_probe(filenames):
     return _wav_probe_c(arr, len(names))
 
 
-def load_wav_batch(filenames, device="cuda:0"):
+def load_wav_batch(filenames, device=None):
     """Many .wav files -> the stream-major device layout.
 
     One pass per file (r3): ``afsk_file_sizes`` (a parallel ``stat``) bounds every file's data chunk,
@@ -466,6 +474,7 @@ def load_wav_batch(filenames, device="cuda:0"):
     the few zero samples its file's header left in its slot)."""
     torch = _torch()
     _native.require_device()
+    device = _default_device(device)
     names = list(filenames)
     if not names:
         return upload_streams([], device)
