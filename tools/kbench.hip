@@ -90,6 +90,62 @@ static void launch_persistent(const DemodArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((persistent_uniform_kernel<STEAL, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b, c);
 }
 
+
+// Third persistent form (r3, second session): FIRST item static (wave w takes stream w, no atomic), the rest
+// of the launch in 8 queues (queue q = streams total + q + 8 j; one 128-byte-padded counter each, so claims
+// do not serialise on one address); a wave claims from the queue of its block's XCD (blocks are dealt
+// round-robin over the 8 XCDs) and, once that is exhausted, looks at all eight counters with one 8-lane load
+// and steals from the first queue that has work left.  Aim: the hardware deals every XCD the same number of
+// blocks although the XCDs are not equally fast (median wave lifetimes differ by ~10 %), so with two items
+// per slot the slow XCDs are the kernel's tail; here a fast XCD's waves take a third item from a slow one.
+template <bool BIG>
+__global__ __launch_bounds__(64 * afsk::kWavesPerBlock) void persistent_xq_kernel(DemodArgs a, unsigned* counters) {
+    using namespace afsk;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kFastWaveLdsProduct];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint8_t* lds = lds_all + wave * kFastWaveLdsProduct;
+    const int total = gridDim.x * kWavesPerBlock;
+    int s = blockIdx.x * kWavesPerBlock + wave;
+    if (s >= a.n_streams) return;
+    process_uniform_stream<KBENCH_BF, 0, BIG>(a, s, lds, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int rest = a.n_streams - total;                      // streams behind the static first items
+    if (rest <= 0) return;
+    int q = blockIdx.x & 7;
+    for (int it = 0; it < (1 << 20); it++) {                   // (bounded on top of the exit condition every wave reaches)
+        const int qlen = (rest - q + 7) >> 3;                  // streams in queue q
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(counters + 32 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int j = (int)__builtin_amdgcn_readfirstlane(v);
+        if (j < qlen) {
+            process_uniform_stream<KBENCH_BF, 0, BIG>(a, total + q + 8 * j, lds, lane);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        // own queue exhausted: one look at all eight counters, then the first queue (from q + 1 on) with work left
+        unsigned c = 0xffffffffu;
+        if (lane < 8) c = __hip_atomic_load(counters + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ql = (rest - (lane & 7) + 7) >> 3;
+        const unsigned long long open = __ballot(lane < 8 && (int)c < ql);
+        if (open == 0) break;
+        const unsigned rot = (unsigned)((open | (open << 8)) >> (q + 1)) & 0xffu;      // bit k = queue (q + 1 + k) & 7
+        q = (q + 1 + __builtin_ctz(rot)) & 7;
+    }
+}
+static unsigned* g_counters_xq = nullptr;    // 256 zeroed words per launch (8 counters, 128 bytes apart)
+static int g_counter_xq_next = 0;
+static void launch_persistent_xq(const DemodArgs& a, hipStream_t s) {
+    DemodArgs b = a;
+    b.uniform_bit_frames = KBENCH_BF;
+    const int blocks = std::min((a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock, 512);
+    unsigned* c = g_counters_xq + 256 * (g_counter_xq_next++ & 16383);
+    if (a.n_streams >= afsk::kHintMinStreamsUniform)
+        hipLaunchKernelGGL((persistent_xq_kernel<true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b, c);
+    else
+        hipLaunchKernelGGL((persistent_xq_kernel<false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b, c);
+}
+
 // same kernel over 4 rotating copies of the input (1.6 GB working set at 4096 streams): defeats
 // any reuse of the 256 MiB Infinity Cache between back-to-back launches
 static const int16_t* g_copies[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -196,8 +252,10 @@ int main(int argc, char** argv) {
         vs.push_back({"uniform skip_valu", launch_uflags<2>, false});
         vs.push_back({"uniform skip_sync+valu", launch_uflags<3>, false});
         CK(hipMalloc(&g_counters, 16384 * sizeof(unsigned))); CK(hipMemset(g_counters, 0, 16384 * sizeof(unsigned)));
+        CK(hipMalloc(&g_counters_xq, 256 * 16384 * sizeof(unsigned))); CK(hipMemset(g_counters_xq, 0, 256 * 16384 * sizeof(unsigned)));
         vs.push_back({"persistent, static stride", launch_persistent<false>, true});
         vs.push_back({"persistent, work stealing", launch_persistent<true>, true});
+        vs.push_back({"persistent, static first + 8 queues", launch_persistent_xq, true});
     }
     if (bfv == KBENCH_BF)
     {   // timeline of one launch of the diagnostic (stamped) build
