@@ -108,6 +108,16 @@ int main(int argc, char** argv) {
             rep(nm, time_us([&] { CK((afsk::launch_modulate_t<1, 1024>(m, L, 0))); }));
             snprintf(nm, 64, "modulate %d q=%d 512thr x2", baud, quirk);
             rep(nm, time_us([&] { CK((afsk::launch_modulate_t<2, 512>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 128thr x8", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<8, 128>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 64thr x8", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<8, 64>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 64thr x16", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<16, 64>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 128thr x4", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<4, 128>(m, L, 0))); }));
+            snprintf(nm, 64, "modulate %d q=%d 128thr x16", baud, quirk);
+            rep(nm, time_us([&] { CK((afsk::launch_modulate_t<16, 128>(m, L, 0))); }));
         }
     }
     return 0;
