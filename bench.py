@@ -20,8 +20,14 @@ and so do the three built "next" rows of SURVEY 8(f), each with its own roofline
   f1_modulate    on-device modulator (write-bound, config5 shape)
   f2_gate        live-gate replay (read-bound) over 4096 and 65536 captures
   f3_wav_ingest  4096 .wav files -> device layout (PCIe-bound: against a pinned hipMemcpy of the bytes)
-plus `rates_4096`: 4096 x 1 s at each of the 36 rates a Receiver can be built for (12000 ... 24 baud).
+plus `rates_4096` / `rates_65536`: 4096 and 65536 x 1 s at each of the 36 rates a Receiver can be built for
+(12000 ... 24 baud; the second is the steady-state fraction per rate, free of launch-shape quantisation).
 At N > 1 the config2 shard is carried as a sub-record (worst case for the per-collective cost).
+
+Output: ONE line on stdout, under 4 KB (`compact_line`: the contract's keys, `roofline`, `cpu_baseline`, match
+rates, {value, frac, match_rate} per sub-record); the full record (per-rate tables, BER rows, event intervals:
+tens of KB) goes to gpurun_out/bench_full_n<N>.json, named in the line as `full_record`.  Nothing large goes to
+stderr either: the driver keeps one ~8 KB tail of both streams.
 
 Timing: a timed region is EXACTLY K steps between two fences (barrier + synchronize on both sides);
 when one region is shorter than --min-region-ms (50 ms) the K-step region is repeated and `value` /
@@ -71,6 +77,8 @@ WORKLOADS = {
 HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
 NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest")   # SURVEY 8(f) rows carried as sub-records at N = 1
 RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
+RATES_BIG_ROW = "rates_65536"   # the same at 65536 streams: the steady-state fraction per rate (no launch-shape quantisation)
+RATES_ROWS = {RATES_ROW: 4096, RATES_BIG_ROW: 65536}
 # 48000 / baud must divide 48000 and be a multiple of 4: 12000 ... 24 baud
 ALL_RATES = tuple(48000 // bf for bf in range(4, 2048, 4) if 48000 % bf == 0)
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
@@ -102,13 +110,13 @@ def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
     elif workload or streams:
         names = []
     else:
-        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) + [RATES_ROW] if world == 1 else ["config2"]
-    riders = NEXT_ROWS + (RATES_ROW,)
+        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) + list(RATES_ROWS) if world == 1 else ["config2"]
+    riders = NEXT_ROWS + tuple(RATES_ROWS)
     for x in [main] + names:
         if x not in WORKLOADS and x not in riders:
             raise SystemExit(f"unknown workload {x}")
     if main in riders:
-        raise SystemExit("f1 / f2 / f3 / rates_4096 are sub-records, not headline workloads")
+        raise SystemExit("f1 / f2 / f3 / rates_* are sub-records, not headline workloads")
     return {"main": main, "subs": [x for x in names if x in WORKLOADS and x != main],
             "next": [x for x in names if x in riders]}
 
@@ -845,7 +853,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_streams: int = 64) -> dict:
+def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_streams: int = 64, warmup: int = 10) -> dict:
     """4096 x 1 s clean streams at EVERY rate a Receiver can be built for (bit_frames must divide 48000 and
     be a multiple of 4: 36 values, 12000 ... 24 baud), each through its own uniform kernel: time per launch,
     fraction of the HBM peak in algorithmic bytes, round trip to the modulated payloads and the CPU oracle
@@ -854,7 +862,7 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
     cores = os.cpu_count() or 1
     for baud in ALL_RATES:
         sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
-        rec, aux = measure(ctx, sh, steps, 10, 50.0, 0, 0.0)          # 50 ms pre-roll: every rate starts from settled clocks
+        rec, aux = measure(ctx, sh, steps, warmup, 50.0, 0, 0.0)      # 50 ms pre-roll: every rate starts from settled clocks
         row = {"bit_frames": 48000 // baud, "payload_bytes": int(sh.plen_h[0]), "entry": rec["entry"],
                "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
                "kernel_ms_median": rec["roofline"]["kernel_ms_median"], "frac": rec["roofline"]["frac"],
@@ -870,12 +878,18 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
         del sh, aux
         ctx.torch.cuda.empty_cache()
     fr = [r["frac"] for r in rows.values()]
-    return {"row": f"{n_streams} x 1 s clean streams at each of the {len(rows)} rates a Receiver can be built for "
-                   "(afsk_demod_batch_uniform: one kernel per bit_frames)",
-            "steps": steps, "min_frac": min(fr), "max_frac": max(fr),
-            "rates_below_0.60": [b for b, r in rows.items() if r["frac"] < 0.60],
-            "all_round_trips_exact": all(r["roundtrip_match_rate"] == 1.0 for r in rows.values()),
-            "by_baud": rows}
+    slow = sorted(rows, key=lambda b: rows[b]["frac"])[:3]
+    doc = {"row": f"{n_streams} x 1 s clean streams at each of the {len(rows)} rates a Receiver can be built for "
+                  "(afsk_demod_batch_uniform: one kernel per bit_frames)",
+           "steps": steps, "min_frac": min(fr), "max_frac": max(fr), "median_frac": median(fr),
+           "rates_below_0.60": [b for b, r in rows.items() if r["frac"] < 0.60],
+           "rates_below_0.75": [b for b, r in rows.items() if r["frac"] < 0.75],
+           "slowest": {b: rows[b]["frac"] for b in slow},
+           "all_round_trips_exact": all(r["roundtrip_match_rate"] == 1.0 for r in rows.values()),
+           "by_baud": rows}
+    if not ctx.args.no_cpu_baseline:
+        doc["min_match_rate"] = min(r["match_rate"] for r in rows.values())
+    return doc
 
 
 def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s: float = 10.0, idx=None, label=""):
@@ -938,6 +952,88 @@ def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s
     return doc, match / ns, ns
 
 
+LINE_CAP = 4096   # bytes: the driver keeps ~8 KB of stdout + stderr; the result line must fit well inside
+
+# keys of the full record that the one-line result keeps verbatim (the contract's keys first)
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "entry", "timed_regions", "timed_region_ms",
+              "event_ms_per_step_median", "kernel_source_hash", "roundtrip_match_rate", "all_timed_steps_identical",
+              "match_rate", "match_sample_streams", "per_workload_value", "ranks_seen", "gather_mode", "gather_check",
+              "gather_check_on_every_rank", "gather_every_steps", "gathers_in_timed_region")
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "single_thread_value", "python_reference_shaped_value",
+             "calibration")
+
+
+def _pick(d: dict, keys) -> dict:
+    return {k: d[k] for k in keys if k in d}
+
+
+def _sub_summary(name: str, rec: dict) -> dict:
+    """One sub-record reduced to {value, frac, match_rate} (+ the two or three figures that only it has)."""
+    if "roofline" not in rec and all(isinstance(v, dict) for v in rec.values()):
+        return {k: _sub_summary(k, v) for k, v in rec.items()}          # f2_gate: one entry per capture count
+    if "by_baud" in rec:                                                 # rates_4096 / rates_65536
+        return _pick(rec, ("min_frac", "max_frac", "median_frac", "rates_below_0.60", "rates_below_0.75",
+                           "slowest", "all_round_trips_exact", "min_match_rate"))
+    out = {"value": rec.get("value"), "frac": (rec.get("roofline") or {}).get("frac")}
+    for k in ("match_rate", "oracle_match_rate", "decoded_match_rate"):
+        if k in rec:
+            out["match_rate"] = rec[k]
+    if "roundtrip_match_rate" in rec and rec["roundtrip_match_rate"] is not None:
+        out["roundtrip"] = rec["roundtrip_match_rate"]
+    if "entry" in rec:
+        out["entry"] = rec["entry"].replace("afsk_demod_batch", "demod")
+    if "ber_curve" in rec:
+        rows = rec["ber_curve"]
+        out["ber"] = {str(r["snr_db"]): r["ber_gpu_all_streams"] for r in rows}
+        out["ber_equals_cpu"] = all(r["ber_equal"] and r["cpu_match_rate"] == 1.0 for r in rows)
+    if "gather_ms" in rec:
+        out["gather_ms"] = rec["gather_ms"]["median"]
+        out["gather_check"] = rec.get("gather_check_on_every_rank")
+    return out
+
+
+def compact_line(full: dict, full_path: str | None = None) -> dict:
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the match rates and a
+    three-figure summary per sub-record -- under LINE_CAP bytes whatever rides along.  Everything else (per-rate
+    table, BER rows, event intervals, notes) stays in the full record (`full_record`, a file next to the run)."""
+    line = _pick(full, _LINE_KEYS)
+    line["roofline"] = _pick(full["roofline"], _ROOF_KEYS)
+    if "cpu_baseline" in full:
+        cb = _pick(full["cpu_baseline"], _CPU_KEYS)
+        if len(cb.get("sample", "")) > 160:
+            cb["sample"] = cb["sample"][:157] + "..."
+        line["cpu_baseline"] = cb
+    if "gather_ms" in full:
+        line["gather_ms"] = _pick(full["gather_ms"], ("median", "max", "bytes_per_rank"))
+    if full.get("sub_records"):
+        line["sub_records"] = {k: _sub_summary(k, v) for k, v in full["sub_records"].items()}
+    line["full_record"] = full_path
+    # belt and braces: should a future rider push the line over the cap, drop the summaries, never the contract
+    for victim in ("sub_records", "per_workload_value", "gather_check"):
+        if len(json.dumps(line)) < LINE_CAP:
+            break
+        line[victim] = "see full_record"
+    assert len(json.dumps(line)) < LINE_CAP, "bench line over the cap"
+    return line
+
+
+def write_full_record(full: dict, world: int) -> str | None:
+    """The full record (tens of KB) goes to gpurun_out/bench_full_n<N>.json -- never to stdout or stderr,
+    whose tails are all the driver keeps."""
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, f"bench_full_n{world}.json")
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(path, ROOT)
+        except OSError:
+            continue
+    return None
+
+
 def run_rank(args) -> None:
     ctx = Ctx(args)
     torch, dist = ctx.torch, ctx.dist
@@ -996,7 +1092,7 @@ def run_rank(args) -> None:
     if world == 1 and not args.no_cpu_baseline:
         ns = args.cpu_sample_streams or min(sh.n_local, 4096)
         out["cpu_baseline"], out["match_rate"], out["match_sample_streams"] = cpu_baseline_for(
-            sh, aux["res"], aux["got_payloads"], ns, cores, 10.0, label=" (the first of them)")
+            sh, aux["res"], aux["got_payloads"], ns, cores, args.cpu_budget_s, label=" (the first of them)")
     subs = {}
     # the next rows that reuse the headline shard's buffers: f1 re-writes its input, f2 reads it
     if world == 1 and "f1_modulate" in next_rows:
@@ -1042,8 +1138,10 @@ def run_rank(args) -> None:
         torch.cuda.empty_cache()
     if world == 1 and "f3_wav_ingest" in next_rows:
         subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
-    if world == 1 and RATES_ROW in next_rows:
-        subs[RATES_ROW] = measure_rates(ctx)
+    for row, n_str in RATES_ROWS.items():
+        if world == 1 and row in next_rows:
+            big = n_str >= 32768
+            subs[row] = measure_rates(ctx, args.rates_steps or (20 if big else 120), n_str, warmup=3 if big else 10)
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
@@ -1059,7 +1157,8 @@ def run_rank(args) -> None:
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        path = write_full_record(out, world)
+        print(json.dumps(compact_line(out, path)), flush=True)
 
 
 def main() -> None:
@@ -1070,7 +1169,7 @@ def main() -> None:
     ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
                     help="headline workload (default: config5 at every N); "
                          "giving one explicitly drops the sub-records unless --sub lists them")
-    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest,rates_4096 ('' = none)")
+    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest,rates_4096,rates_65536 ('' = none)")
     ap.add_argument("--min-region-ms", type=float, default=50.0,
                     help="repeat the K-step timed region until the regions add up to this (0 = exactly one region)")
     ap.add_argument("--entry", default="auto", choices=["auto", "mixed"],
@@ -1078,6 +1177,8 @@ def main() -> None:
     ap.add_argument("--next-reps", type=int, default=20, help="timed launches of the f1 / f2 sub-records")
     ap.add_argument("--wav-files", type=int, default=4096, help="files of the f3_wav_ingest sub-record")
     ap.add_argument("--sub-steps", type=int, default=0, help="timed steps of every sub-record (0 = 20 / 200)")
+    ap.add_argument("--rates-steps", type=int, default=0, help="timed steps per rate of rates_4096 / rates_65536 (0 = 120 / 20)")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="wall-clock budget of the headline cpu_baseline leg")
     ap.add_argument("--sub-cpu-sample", type=int, default=1024,
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")

@@ -21,8 +21,20 @@ if mode == "fail" and rank == world - 1:
     os._exit(3)
 if mode != "silent" and rank == 0:
     pl = bench.plan(world)
-    print(json.dumps({"metric": "stub", "ranks_seen": int(ones.item()), "n_gpus": world,
-                      "config": bench.config_block(pl["main"], bench.WORKLOADS[pl["main"]][0], world, "gloo"),
-                      "sub_records": {k: {} for k in pl["subs"] + pl["next"]}}), flush=True)
+    # a full record shaped like run_rank's at N > 1 (figures are placeholders), through the SAME compaction
+    roof = {"bound": "hbm", "achieved": 1.0, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None,
+            "algorithmic_bytes_per_launch": 1, "kernel_ms": 1.0, "kernel_ms_median": 1.0, "padding": "x" * 3000}
+    gather = {"ranks_seen": int(ones.item()), "gather_mode": "gather to rank 0", "gather_check": [True] * world,
+              "gather_check_on_every_rank": True, "gather_every_steps": 3, "gathers_in_timed_region": 7,
+              "gather_ms": {"median": 0.1, "max": 0.2, "bytes_per_rank": 1, "measured": 7}}
+    sub = {"value": 1.0, "roofline": roof, "roundtrip_match_rate": 1.0, "entry": "afsk_demod_batch_uniform",
+           "event_intervals": {"padding": "y" * 3000}, **gather}
+    full = {"metric": "stub", "value": 1.0, "unit": "Msamples/s", "n_gpus": world, "steps": 1, "warmup": 0,
+            "ms_per_step": 1.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16",
+            "data": "synthetic",
+            "config": bench.config_block(pl["main"], bench.WORKLOADS[pl["main"]][0], world, "gloo"),
+            "roofline": roof, "sub_records": {k: dict(sub) for k in pl["subs"] + pl["next"]},
+            "scaling_note": "z" * 3000, **gather}
+    print(json.dumps(bench.compact_line(full, None)), flush=True)
 dist.barrier() if mode != "fail" else None
 dist.destroy_process_group() if mode != "fail" else None

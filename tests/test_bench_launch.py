@@ -13,6 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STUB = os.path.join(ROOT, "tests", "helpers", "stub_rank.py")
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+
+
+def bench_mod():
+    import bench
+    return bench
+
+
 def _launch(mode):
     import bench
     buf = io.StringIO()
@@ -28,6 +38,11 @@ def test_launcher_relays_rank0_line_only():
     assert len(lines) == 1, out                      # ONE JSON line on stdout, the chatter went to stderr
     doc = json.loads(lines[0])
     assert doc["ranks_seen"] == 2 and doc["n_gpus"] == 2
+    # the N > 1 line obeys the same cap as the N = 1 line and still carries what the scaling run is judged on
+    assert len(lines[0]) < bench_mod().LINE_CAP
+    assert doc["gather_check"] == [True, True] and doc["gather_ms"]["median"] == 0.1
+    assert set(CONTRACT_KEYS) <= set(doc), set(CONTRACT_KEYS) - set(doc)
+    assert doc["sub_records"]["config2"]["gather_check"] is True
 
 
 def test_launcher_nonzero_when_a_rank_fails():
@@ -71,7 +86,7 @@ def test_headline_workload_is_the_same_at_every_n():
     assert blocks[1]["workload"] == blocks[2]["workload"] == blocks[8]["workload"]
     assert blocks[8]["streams_total"] == 524288
     one, two = bench.plan(1), bench.plan(2)
-    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS) + [bench.RATES_ROW]
+    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS) + ["rates_4096", "rates_65536"]
     assert len(bench.ALL_RATES) == 36 and set((300, 1200, 2400, 100, 160, 96, 24, 12000)) <= set(bench.ALL_RATES)
     assert two["subs"] == ["config2"] and two["next"] == []
     # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline
@@ -90,3 +105,52 @@ def test_stub_rank_line_names_the_headline_workload():
     assert rc == 0
     doc = json.loads([ln for ln in out.splitlines() if ln.strip()][0])
     assert doc["config"]["workload"] == bench.config_block(bench.plan(1)["main"], 65536, 1)["workload"]
+
+
+@pytest.mark.parametrize("record", ["r3_bench_n1.json", "r3_bench_n8_diagnostic_gloo_shared_gpu.json",
+                                    "r2_bench_n1.json"])
+def test_result_line_is_compact_and_complete(record):
+    """The contract that broke in round 3 (a 26 KB line, of which the driver kept the last 8 KB): whatever the full
+    record holds, the ONE line on stdout stays under LINE_CAP and keeps every key the driver and the judge parse."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", record)))
+    line = bench.compact_line(full, "gpurun_out/bench_full_n1.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_CAP <= 4096, len(text)
+    assert set(CONTRACT_KEYS) <= set(line)
+    assert set(ROOF_KEYS) <= set(line["roofline"]) and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert line["value"] == full["value"] and line["config"] == full["config"]
+    assert line["full_record"] == "gpurun_out/bench_full_n1.json"
+    if full["n_gpus"] == 1:
+        cb = line["cpu_baseline"]
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["value"] == full["cpu_baseline"]["value"]
+        assert line["match_rate"] == full["match_rate"]
+    else:
+        assert line["ranks_seen"] == full["ranks_seen"] and line["gather_check"] == full["gather_check"]
+    for name, sub in (full.get("sub_records") or {}).items():
+        got = line["sub_records"][name]
+        if "roofline" in sub:
+            assert got["frac"] == sub["roofline"]["frac"] and got["value"] == sub["value"]
+
+
+def test_result_line_survives_a_bloated_record():
+    """Riders that do not exist yet cannot push the line over the cap: the summaries go, the contract stays."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    full["sub_records"].update({f"future_{i}": {"value": i, "roofline": {"frac": 0.5}, "match_rate": 1.0,
+                                                "entry": "e" * 40} for i in range(200)})
+    line = bench.compact_line(full, None)
+    assert len(json.dumps(line)) < bench.LINE_CAP
+    assert set(CONTRACT_KEYS) <= set(line) and line["sub_records"] == "see full_record"
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and "cpu_baseline" in line
+
+
+def test_full_record_goes_to_a_file_not_to_the_streams(tmp_path, monkeypatch, capsys):
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    path = bench.write_full_record(full, 1)
+    assert path == os.path.join("gpurun_out", "bench_full_n1.json")
+    assert json.load(open(tmp_path / path)) == full
+    cap = capsys.readouterr()
+    assert cap.out == "" and cap.err == ""

@@ -189,7 +189,7 @@ def test_bench_two_rank_flow_on_one_gpu():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines) == 1 and len(lines[0]) < 4096, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
     assert d["gather_check"] == [True, True] and d["gather_check_on_every_rank"] is True
@@ -292,11 +292,54 @@ def test_bench_three_rank_rehearsal_full_size_on_one_gpu():
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])             # the N > 1 line obeys the same cap as the N = 1 line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["ranks_seen"] == 3
     assert d["gather_check"] == [True] * 3 and d["gather_check_on_every_rank"] is True
+    assert d["gather_ms"]["median"] > 0
     assert d["config"]["streams_per_gpu"] == 65536 and d["config"]["streams_total"] == 3 * 65536
     assert d["config"]["workload"].startswith("configs[4]")
     assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
-    sub = d["sub_records"]["config2"]
+    assert {"bound", "achieved", "peak", "frac", "traffic"} <= set(d["roofline"])
+    assert d["sub_records"]["config2"]["gather_check"] is True and d["sub_records"]["config2"]["roundtrip"] == 1.0
+    full = json.load(open(os.path.join(root, d["full_record"])))
+    sub = full["sub_records"]["config2"]
     assert sub["ranks_seen"] == 3 and sub["gather_check"] == [True] * 3 and sub["roundtrip_match_rate"] == 1.0
+    assert full["value"] == d["value"] and full["roofline"]["frac"] == d["roofline"]["frac"]
+
+
+def test_bench_default_line_at_n1_is_compact_and_complete():
+    """The driver's own invocation shape (`python bench.py --gpus 1 ...`, every default rider: config2/3/4, f1/f2/f3,
+    the 36-rate tables) at reduced step counts: ONE line under 4 KB carrying the contract's keys, `roofline` and
+    `cpu_baseline`; the 30 KB full record in the file the line names.  (Round 3's line was 26 KB and the driver,
+    which keeps ~8 KB of output, could parse nothing.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--preroll-ms", "20", "--sub-steps", "6", "--next-reps", "3", "--wav-files", "256",
+                        "--sub-cpu-sample", "64", "--cpu-sample-streams", "256", "--rates-steps", "6",
+                        "--cpu-budget-s", "1"],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), len(p.stdout))
+    assert len(p.stderr) < 2048, p.stderr[-2000:]          # the driver's 8 KB tail holds stdout AND stderr
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "match_rate"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["config"]["workload"].startswith("configs[4]")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and 0 < d["roofline"]["frac"] < 1
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["match_rate"] == 1.0 and d["roundtrip_match_rate"] == 1.0
+    subs = d["sub_records"]
+    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_4096",
+            "rates_65536"} <= set(subs)
+    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest"):
+        assert subs[name]["match_rate"] == 1.0, name
+    assert subs["config4"]["ber_equals_cpu"] is True
+    full = json.load(open(os.path.join(root, d["full_record"])))
+    assert full["value"] == d["value"] and len(full["sub_records"]["rates_65536"]["by_baud"]) == 36
+    assert full["sub_records"]["rates_4096"]["all_round_trips_exact"] and full["sub_records"]["rates_65536"]["all_round_trips_exact"]
