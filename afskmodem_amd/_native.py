@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("AFSK_AMD_LIB") or os.path.join(_HERE, "csrc", "libafs
 
 OK = 0
 E_INVALID_ARG, E_INVALID_BAUD, E_NO_DEVICE, E_HIP, E_HOST = -1, -2, -3, -4, -5
-ST_OK, ST_TOO_SHORT, ST_NO_DATA, ST_INVALID_BAUD = 0, 1, 2, 3
+ST_OK, ST_TOO_SHORT, ST_NO_DATA, ST_INVALID_BAUD, ST_BAD_LENGTH = 0, 1, 2, 3, 4
 WAV_OK = 0
 WAV_SLOT = 5
 
@@ -56,6 +56,13 @@ SIGNATURES = {
                                            C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
+    "afsk_group_plan_create": (C.c_int, [_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "afsk_group_plan_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, C.c_int32]),
+    "afsk_group_plan_destroy": (C.c_int, [C.c_void_p]),
+    "afsk_demod_batch_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p]),
     "afsk_demod_batch_host": (C.c_int, [_i16p, C.c_int64, _i64p, _i32p, _i32p, C.c_int32,
                                         C.c_int32, _u8p, C.c_int32, _i32p, _i32p, _i32p, _i32p,
                                         _i32p]),

@@ -240,38 +240,120 @@ def _order_after_current(stream, device) -> None:
             stream.wait_stream(cur)
 
 
-def _uniform_bit_frames(bit_frames):
-    """The one value of a host-side bit_frames argument (int, or a sequence / array whose entries
-    are all equal), else None.  Device tensors are never inspected (that would synchronise)."""
+def _uniform_bit_frames(bit_frames, n: int):
+    """The one value of a host-side bit_frames argument (int, or a sequence / array of 1 or n entries that
+    are all equal), else None.  Device tensors are never inspected (that would synchronise).  A host
+    sequence must hold 1 or n values (what ``np.broadcast_to`` accepts), whichever entry it ends up in."""
     if isinstance(bit_frames, (int, np.integer)):
         return int(bit_frames)
     if isinstance(bit_frames, (list, tuple, np.ndarray)):
         arr = np.asarray(bit_frames)
         if arr.ndim == 0:
             return int(arr)
+        if arr.size not in (1, n):
+            raise ValueError(f"bit_frames holds {arr.size} values for {n} streams (1 or {n} expected)")
         if arr.size and np.all(arr == arr.flat[0]):
             return int(arr.flat[0])
     return None
 
 
+_PLAN_CACHE: "dict[tuple, GroupPlan]" = {}
+_PLAN_CACHE_MAX = 8
+
+
+def _cached_plan(bit_frames, n: int, dev) -> "GroupPlan":
+    """Plans built on behalf of ``demod_batch`` calls that did not bring one: kept per (device, contents)
+    so that decoding the same batch layout again costs one hash of the array, and freed -- after a
+    device synchronise, launches may still be queued -- only when eight newer layouts have displaced them."""
+    arr = np.asarray(bit_frames, dtype=np.int32)
+    if arr.size not in (1, n):
+        raise ValueError(f"bit_frames holds {arr.size} values for {n} streams (1 or {n} expected)")
+    arr = np.ascontiguousarray(np.broadcast_to(arr.reshape(-1) if arr.ndim else arr, (n,)))
+    key = (str(dev), n, hash(arr.tobytes()))
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None and np.array_equal(plan.bit_frames, arr):
+        _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)          # most recently used last
+        return plan
+    plan = GroupPlan(arr, dev)
+    _PLAN_CACHE[key] = plan
+    while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+        old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _torch().cuda.synchronize(old.device)
+        old.close()
+    return plan
+
+
+class GroupPlan:
+    """Rate-grouped dispatch plan of a mixed-baud batch whose ``bit_frames`` the host can see
+    (``afsk_group_plan_create``): the streams bucketed by rate, one uniform-kernel launch per rate on forked
+    side streams, outputs at the original stream numbers.  Build it once per batch layout and pass it to
+    ``demod_batch(..., plan=...)``; it belongs to the device that was current when it was built."""
+
+    def __init__(self, bit_frames, device=None):
+        torch = _torch()
+        _native.require_device()
+        self.bit_frames = np.ascontiguousarray(np.asarray(bit_frames, dtype=np.int32).reshape(-1))
+        self.n = int(self.bit_frames.size)
+        self.device = _default_device(device)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _native.check(_native.lib().afsk_group_plan_create(
+                self.bit_frames.ctypes.data_as(C.POINTER(C.c_int32)), self.n, C.byref(self._h)))
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ValueError("the plan has been closed")
+        return self._h
+
+    def groups(self) -> list[tuple[int, int]]:
+        """[(bit_frames, streams)] per launch, in launch order (bit_frames 0 = refused streams)."""
+        ng, nn = C.c_int32(), C.c_int32()
+        lib = _native.lib()
+        _native.check(lib.afsk_group_plan_info(self.handle, C.byref(nn), C.byref(ng), None, None, 0))
+        bf, cnt = (C.c_int32 * max(ng.value, 1))(), (C.c_int32 * max(ng.value, 1))()
+        _native.check(lib.afsk_group_plan_info(self.handle, None, None, bf, cnt, ng.value))
+        return [(int(bf[k]), int(cnt[k])) for k in range(ng.value)]
+
+    def close(self) -> None:
+        """Free the plan (after the launches that use it have completed)."""
+        if self._h:
+            _native.lib().afsk_group_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self._h:
+                _torch().cuda.synchronize(self.device)     # launches may still be queued
+                self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshold: int = 14000,
                 out: DemodResult | None = None, out_stride: int | None = None, stream=None,
                 validate: bool = True, diagnostics: bool = False,
-                margin_stride: int | None = None, entry: str = "auto") -> DemodResult:
+                margin_stride: int | None = None, entry: str = "auto", plan: "GroupPlan | None" = None) -> DemodResult:
     """One kernel launch over n independent streams resident in HBM.
 
     samples        int16 CUDA tensor holding every stream
     stream_offset  int64 CUDA tensor [n], first sample of each stream
     stream_len     int32 CUDA tensor [n]
     bit_frames     48000 / baud: an int (one Receiver's batch: ref:275-284), or a sequence /
-                   tensor [n] with one value per stream
+                   tensor [n] with one value per stream (None with ``plan=``)
     out            preallocated DemodResult to reuse (no allocation in the call)
     diagnostics    also return the soft outputs: ``corrected`` [n] and ``margins`` [n, margin_stride]
                    (margin_stride symbols per row; pass e.g. max_stream_len // min(bit_frames));
                    rows are defined up to ``DemodResult.symbols_demodulated``
     entry          "auto": ``afsk_demod_batch_uniform`` (a kernel compiled for exactly that
-                   geometry) when the host can see that bit_frames is one value, else the
-                   per-stream ``afsk_demod_batch`` / ``_ex``; "uniform" / "mixed" force one
+                   geometry) when the host can see that bit_frames is one value;
+                   ``afsk_demod_batch_grouped`` (one such kernel per rate, concurrently) when it can
+                   see several (a host sequence / array, or ``plan=``); the per-stream
+                   ``afsk_demod_batch`` / ``_ex`` for a device tensor.  "uniform" / "grouped" / "mixed"
+                   force one.  The uniform entry raises AFSK_E_INVALID_BAUD for an invalid value
+                   (``validate=False``); the grouped and mixed entries write status 3 for such streams.
+    plan           a ``GroupPlan`` built from this batch's host-side bit_frames: reused across calls
+                   (otherwise "grouped" builds one per call: a sort and an n * 4 byte upload)
     Asynchronous on ``stream`` (default: torch's current stream).
     """
     torch = _torch()
@@ -280,11 +362,13 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         raise TypeError("samples must be an int16 CUDA tensor (HBM resident)")
     if not samples.is_contiguous():
         raise ValueError("samples must be contiguous")
-    if entry not in ("auto", "uniform", "mixed"):
-        raise ValueError("entry must be 'auto', 'uniform' or 'mixed'")
+    if entry not in ("auto", "uniform", "grouped", "mixed"):
+        raise ValueError("entry must be 'auto', 'uniform', 'grouped' or 'mixed'")
     n = int(stream_offset.numel())
     dev = samples.device
-    if validate and not isinstance(bit_frames, torch.Tensor):
+    if bit_frames is None and plan is None:
+        raise ValueError("bit_frames=None needs plan= (the plan holds the batch's bit_frames)")
+    if validate and bit_frames is not None and not isinstance(bit_frames, torch.Tensor):
         validate_bit_frames(bit_frames)
     if stream_offset.dtype != torch.int64 or stream_len.dtype != torch.int32:
         raise TypeError("stream_offset must be int64 and stream_len int32")
@@ -293,9 +377,19 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
     _same_device(dev, stream_offset=stream_offset, stream_len=stream_len)
     if not (stream_offset.is_contiguous() and stream_len.is_contiguous()):
         raise ValueError("stream_offset / stream_len must be contiguous (the kernel reads them as plain arrays)")
-    ubf = None if entry == "mixed" else _uniform_bit_frames(bit_frames)
+    host_bf = isinstance(bit_frames, (int, np.integer, list, tuple, np.ndarray))
+    if plan is not None:
+        if entry not in ("auto", "grouped"):
+            raise ValueError("plan= goes with entry='auto' or 'grouped'")
+        if plan.n != n or plan.device != dev:
+            raise ValueError(f"the plan covers {plan.n} streams on {plan.device}, the batch {n} on {dev}")
+        entry = "grouped"
+    ubf = None if entry in ("mixed", "grouped") else _uniform_bit_frames(bit_frames, n)
     if entry == "uniform" and ubf is None:
         raise ValueError("entry='uniform' needs ONE bit_frames value (an int or an all-equal host sequence)")
+    if entry == "grouped" and plan is None and not host_bf:
+        raise ValueError("entry='grouped' needs host-side bit_frames (or plan=): a device tensor is never inspected")
+    grouped = entry == "grouped" or (entry == "auto" and ubf is None and host_bf)
     fresh = False                      # tensors created (zero-filled / uploaded) inside this call
     if out is None:
         if out_stride is None:
@@ -325,6 +419,15 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
             _native.check(lib.afsk_demod_batch_uniform(
                 samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), ubf,
                 threshold_lt(amp_end_threshold), n, out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+                out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+                out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
+            return out
+        if grouped:
+            if plan is None:
+                plan = _cached_plan(bit_frames, n, dev)
+            _native.check(lib.afsk_demod_batch_grouped(
+                plan.handle, samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
+                threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
                 out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
                 out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
             return out

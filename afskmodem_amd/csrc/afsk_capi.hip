@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -420,6 +421,122 @@ int wav_probe_fd(int fd, int64_t* data_off, int64_t* data_bytes) {
     return rc;
 }
 
+
+// ---- rate-grouped dispatch of a mixed-baud batch (afsk_demod_batch_grouped) -----------------------------
+// The host can see bit_frames: the streams are bucketed by value, every bucket is one launch of the uniform
+// kernel compiled for exactly that symbol geometry (wave w of the launch decodes stream index[first + w]),
+// and the launches run CONCURRENTLY on side streams forked from and joined back into the caller's stream
+// with events only (no host synchronisation: the pattern a stream capture records as a fork / join).
+struct GroupPlan {
+    struct Group { int32_t bf; int32_t first; int32_t count; };
+    static constexpr int kMaxSide = 7;           // concurrent launches besides the caller's stream
+    int device = -1;
+    int32_t n = 0;
+    std::vector<Group> groups;                   // valid rates, largest bucket first; then bf <= 0: refused streams
+    std::vector<int32_t> h_index;                // the permutation, bucket after bucket
+    int32_t* d_index = nullptr;
+    bool own_index = false;
+    hipStream_t side[kMaxSide] = {};
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[kMaxSide] = {};
+    int n_side = 0;
+
+    ~GroupPlan() {
+        for (int k = 0; k < kMaxSide; k++) {
+            if (join[k]) (void)hipEventDestroy(join[k]);
+            if (side[k]) (void)hipStreamDestroy(side[k]);
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        if (own_index && d_index) (void)hipFree(d_index);
+    }
+
+    static bool valid_bf(int32_t bf) { return bf >= 4 && (bf & 3) == 0 && 2 * bf < AFSK_SYNC_WINDOW; }
+
+    // host part: buckets and permutation (stable inside a bucket: ascending stream number)
+    void bucket(const int32_t* h_bf, int32_t n_streams) {
+        n = n_streams;
+        std::vector<int32_t> count(AFSK_SYNC_WINDOW / 2 + 1, 0);    // slot 0 = every invalid value
+        auto slot = [](int32_t bf) { return valid_bf(bf) ? bf : 0; };
+        for (int32_t s = 0; s < n; s++) count[(size_t)slot(h_bf[s])]++;
+        std::vector<int32_t> order;
+        for (int32_t bf = 4; bf < (int32_t)count.size(); bf += 4)
+            if (count[(size_t)bf]) order.push_back(bf);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return count[(size_t)a] > count[(size_t)b]; });
+        if (count[0]) order.push_back(0);
+        std::vector<int32_t> cursor(count.size(), 0);
+        int32_t first = 0;
+        for (int32_t bf : order) {
+            groups.push_back({bf, first, count[(size_t)bf]});
+            cursor[(size_t)bf] = first;
+            first += count[(size_t)bf];
+        }
+        h_index.resize((size_t)n);
+        for (int32_t s = 0; s < n; s++) h_index[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+    }
+
+    // device part: side streams + events on the current device; the index list either in storage the caller
+    // provides (copied asynchronously on `copy_stream`, which every launch of this plan must follow) or in an
+    // allocation of its own (copied synchronously)
+    hipError_t materialise(int32_t* index_storage, hipStream_t copy_stream) {
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        int launches = 0;
+        for (const Group& g : groups) launches += g.count > 0;
+        n_side = std::min<int>(kMaxSide, std::max(0, launches - 1));
+        if (n_side > 0) {
+            e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+            if (e != hipSuccess) { fork = nullptr; return e; }
+        }
+        for (int k = 0; k < n_side; k++) {
+            e = hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking);
+            if (e != hipSuccess) { side[k] = nullptr; return e; }
+            e = hipEventCreateWithFlags(&join[k], hipEventDisableTiming);
+            if (e != hipSuccess) { join[k] = nullptr; return e; }
+        }
+        if (n == 0) return hipSuccess;
+        if (index_storage) {
+            d_index = index_storage;
+            return hipMemcpyAsync(d_index, h_index.data(), (size_t)n * 4, hipMemcpyHostToDevice, copy_stream);
+        }
+        e = hipMalloc((void**)&d_index, (size_t)n * 4);
+        if (e != hipSuccess) { d_index = nullptr; return e; }
+        own_index = true;
+        return hipMemcpy(d_index, h_index.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    }
+
+    // one launch per bucket: bucket 0 on the caller's stream, the others round-robin on the side streams
+    hipError_t launch(afsk::DemodArgs a, hipStream_t stream) const {
+        hipError_t e = hipSuccess;
+        if (n_side > 0) {
+            e = hipEventRecord(fork, stream);
+            if (e != hipSuccess) return e;
+            for (int k = 0; k < n_side; k++) {
+                e = hipStreamWaitEvent(side[k], fork, 0);
+                if (e != hipSuccess) return e;
+            }
+        }
+        int li = 0;
+        for (const Group& g : groups) {
+            if (g.count <= 0) continue;
+            hipStream_t st = (li == 0 || n_side == 0) ? stream : side[(li - 1) % n_side];
+            li++;
+            a.stream_index = d_index + g.first;
+            a.n_streams = g.count;
+            a.bit_frames = nullptr;
+            a.uniform_bit_frames = g.bf;
+            e = g.bf > 0 ? afsk::launch_demod_uniform(a, st) : afsk::launch_refuse(a, AFSK_ST_INVALID_BAUD, st);
+            if (e != hipSuccess) break;
+        }
+        // join even after a failed launch: the caller's stream must not run ahead of launches already queued
+        for (int k = 0; k < n_side; k++) {
+            hipError_t e2 = hipEventRecord(join[k], side[k]);
+            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(stream, join[k], 0);
+            if (e == hipSuccess) e = e2;
+        }
+        return e;
+    }
+};
+
 #define AFSK_HIP(call, what)                             \
     do {                                                 \
         hipError_t e_ = (call);                          \
@@ -539,21 +656,99 @@ int afsk_demod_batch_uniform(const int16_t* samples, const int64_t* stream_offse
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel");
 }
 
-// The host entries see the bit_frames array: one value for all streams -> the uniform kernel.
+struct afsk_group_plan { GroupPlan p; };
+
+int afsk_group_plan_create(const int32_t* bit_frames_host, int32_t n_streams, afsk_group_plan** out_plan) {
+    if (!out_plan) return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    *out_plan = nullptr;
+    if (n_streams < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (n_streams > 0 && !bit_frames_host) return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    if (int rc = require_device()) return rc;
+    return no_throw([&] {
+        std::unique_ptr<afsk_group_plan> pl(new afsk_group_plan());
+        pl->p.bucket(bit_frames_host, n_streams);
+        hipError_t e = pl->p.materialise(nullptr, nullptr);
+        if (e != hipSuccess) return hip_fail(e, "afsk_group_plan_create (streams / events / index list)");
+        *out_plan = pl.release();
+        return AFSK_OK;
+    });
+}
+
+int afsk_group_plan_info(const afsk_group_plan* plan, int32_t* out_n_streams, int32_t* out_n_groups,
+                         int32_t* out_group_bit_frames, int32_t* out_group_count, int32_t cap) {
+    if (!plan) return fail(AFSK_E_INVALID_ARG, "null plan");
+    if (out_n_streams) *out_n_streams = plan->p.n;
+    if (out_n_groups) *out_n_groups = (int32_t)plan->p.groups.size();
+    for (int32_t k = 0; k < cap && k < (int32_t)plan->p.groups.size(); k++) {
+        if (out_group_bit_frames) out_group_bit_frames[k] = plan->p.groups[(size_t)k].bf;
+        if (out_group_count) out_group_count[k] = plan->p.groups[(size_t)k].count;
+    }
+    return AFSK_OK;
+}
+
+int afsk_group_plan_destroy(afsk_group_plan* plan) {
+    delete plan;      // streams, events and the index list; the caller has synchronised its launches
+    return AFSK_OK;
+}
+
+int afsk_demod_batch_grouped(const afsk_group_plan* plan, const int16_t* samples,
+                             const int64_t* stream_offset, const int32_t* stream_len,
+                             int32_t amp_end_threshold, uint8_t* out_bytes, int32_t out_stride,
+                             int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
+                             int32_t* out_term_frame, int32_t* out_status, int32_t* out_corrected,
+                             int32_t* out_margins, int32_t margin_stride, void* hip_stream) {
+    if (!plan) return fail(AFSK_E_INVALID_ARG, "null plan");
+    if (out_stride < 0 || margin_stride < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (plan->p.n == 0) return AFSK_OK;
+    if (!samples || !stream_offset || !stream_len || !out_nbytes || !out_nbits ||
+        !out_clock_idx || !out_term_frame || !out_status || (!out_bytes && out_stride > 0))
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    if (int rc = require_device()) return rc;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != plan->p.device)
+        return fail(AFSK_E_INVALID_ARG, "the plan was created on another device than the current one");
+    afsk::DemodArgs a;
+    a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
+    a.amp_end = amp_end_threshold;
+    a.out_bytes = out_bytes; a.out_stride = out_stride; a.out_nbytes = out_nbytes;
+    a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
+    a.out_status = out_status;
+    a.out_corrected = out_corrected;
+    a.out_margins = margin_stride > 0 ? out_margins : nullptr;
+    a.margin_stride = margin_stride;
+    hipError_t e = plan->p.launch(a, (hipStream_t)hip_stream);
+    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel (grouped)");
+}
+
+// The host entries see the bit_frames array: one value for all streams -> the uniform kernel;
+// several -> one uniform launch per rate (the index list lives in `index_storage`, n int32 of the
+// caller's device scratch; `keep` owns the side streams until the caller has synchronised).
 static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples, const int64_t* stream_offset,
                              const int32_t* stream_len, const int32_t* d_bit_frames, int32_t amp_end_threshold,
                              int32_t n_streams, uint8_t* out_bytes, int32_t out_stride, int32_t* out_nbytes,
                              int32_t* out_nbits, int32_t* out_clock_idx, int32_t* out_term_frame,
-                             int32_t* out_status, hipStream_t stream) {
+                             int32_t* out_status, hipStream_t stream, int32_t* index_storage,
+                             std::unique_ptr<GroupPlan>& keep) {
+    (void)d_bit_frames;
     bool same = true;
     for (int32_t s = 1; s < n_streams && same; s++) same = h_bit_frames[s] == h_bit_frames[0];
     if (same)
         return afsk_demod_batch_uniform(samples, stream_offset, stream_len, h_bit_frames[0], amp_end_threshold,
                                         n_streams, out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx,
                                         out_term_frame, out_status, nullptr, nullptr, 0, stream);
-    return afsk_demod_batch(samples, stream_offset, stream_len, d_bit_frames, amp_end_threshold, n_streams,
-                            out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx, out_term_frame,
-                            out_status, stream);
+    if (int rc = require_device()) return rc;
+    keep.reset(new GroupPlan());
+    keep->bucket(h_bit_frames, n_streams);
+    hipError_t e = keep->materialise(index_storage, stream);
+    if (e != hipSuccess) return hip_fail(e, "grouped dispatch (streams / events / index list)");
+    afsk::DemodArgs a;
+    a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
+    a.amp_end = amp_end_threshold;
+    a.out_bytes = out_bytes; a.out_stride = out_stride; a.out_nbytes = out_nbytes;
+    a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
+    a.out_status = out_status;
+    e = keep->launch(a, stream);
+    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel (grouped)");
 }
 
 static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
@@ -595,6 +790,7 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
         if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
     }
     ScratchLease lease;
+    std::unique_ptr<GroupPlan> plan;      // mixed rates: side streams + events, alive until the final synchronise
     char* d_all = nullptr;
     // host staging: one H2D for the three index arrays, one D2H for all six outputs
     std::vector<char> h_meta(meta_bytes), h_out(out_bytes_total);
@@ -616,7 +812,9 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
                                (const int32_t*)(d_all + o_meta + n * 8),
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
-                               i32 + 3 * n, i32 + 4 * n, stream);
+                               i32 + 3 * n, i32 + 4 * n, stream,
+                               (int32_t*)(d_all + o_meta + n * 12),   // a grouped launch reads no bit_frames[]: its slot holds the index list
+                               plan);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -702,6 +900,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
         if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
     }
     ScratchLease lease;
+    std::unique_ptr<GroupPlan> plan;      // mixed rates: side streams + events, alive until the final synchronise
     char* d_all = nullptr;
     char* stage[2];
     hipEvent_t stage_free[2];
@@ -747,7 +946,9 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
                                (const int32_t*)(d_all + o_meta + n * 8),
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
-                               i32 + 3 * n, i32 + 4 * n, stream);
+                               i32 + 3 * n, i32 + 4 * n, stream,
+                               (int32_t*)(d_all + o_meta + n * 12),   // a grouped launch reads no bit_frames[]: its slot holds the index list
+                               plan);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -1141,6 +1342,7 @@ int afsk_gate_batch(const int16_t* samples, const int64_t* stream_offset,
     afsk::GateArgs a;
     a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
     a.amp_start = amp_start_threshold; a.amp_end = amp_end_threshold; a.n_streams = n_streams;
+    a.max_len = max_stream_len;
     a.max_blocks = max_blocks; a.max_bursts = max_bursts; a.block_amp = block_amp;
     a.out_n_bursts = out_n_bursts; a.out_burst_start = out_burst_start;
     a.out_burst_len = out_burst_len; a.out_open_end = out_open_end;

@@ -200,6 +200,13 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 // mixed-baud launch they run the run-time geometry (the per-stream switch stays at AFSK_FAST_BF_LIST).
 #define AFSK_GP_BF_LIST(X) X(128) X(192) X(200) X(300) X(384) X(400) X(500) X(600) X(640) X(800) X(960) X(1000) X(1200) X(1500) X(1600) X(1920) X(2000)
 
+// how many uniform kernels the build must produce (build.sh scrapes the two lists above and checks its
+// count against this line, so a reformatted macro cannot silently drop kernels from the library)
+#define AFSK_X(B) +1
+constexpr int kUniformBfCount = 0 AFSK_FAST_BF_LIST(AFSK_X) AFSK_GP_BF_LIST(AFSK_X);
+#undef AFSK_X
+static_assert(kUniformBfCount == 36, "every bit_frames a Receiver can be built for has a compile-time geometry");
+
 __host__ __device__ constexpr bool bit_frames_valid(int bf) {       // ref:68-85, 327: templates exist, sync window fits
     return bf >= 4 && (bf & 3) == 0 && 2 * bf < kSync;
 }
@@ -217,7 +224,8 @@ __host__ __device__ constexpr bool has_uniform_geometry(int bf) {     // compile
 }
 
 // streams the decoder refuses before touching a sample: status 3 (invalid bit_frames; the host
-// validates first, this only keeps the kernel memory-safe) or 1 (shorter than the sync window, ref:323-325)
+// validates first, this only keeps the kernel memory-safe), 4 (stream_len negative or above
+// AFSK_MAX_STREAM_LEN: device-side arrays the host never saw) or 1 (shorter than the sync window, ref:323-325)
 __device__ __forceinline__ void store_refusal(const DemodArgs& a, int s, int lane, int32_t status) {
     if (lane == 0) {
         a.out_nbytes[s] = 0; a.out_nbits[s] = 0; a.out_clock_idx[s] = -1;
@@ -245,6 +253,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     const int16_t* xs = a.samples + off;
     uint8_t* out_row = a.out_bytes + (int64_t)s * a.out_stride;
     if (!bit_frames_valid(bf)) { store_refusal(a, s, lane, 3); return; }
+    if ((uint32_t)len > (uint32_t)kMaxStreamLen) { store_refusal(a, s, lane, 4); return; }   // negative or beyond 32-bit byte offsets
     if (len < kSync) { store_refusal(a, s, lane, 1); return; }
     RxState st;
     int32_t n_sym = 0;
@@ -299,6 +308,8 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
 template <int BF, int FLAGS, bool BIG>
 __device__ __forceinline__ void process_uniform_stream(const DemodArgs& a, int s, uint8_t* lds, int lane) {
     const int32_t len = a.stream_len[s];
+    // a DEVICE-side length the host never saw: negative, or beyond what 32-bit byte offsets address
+    if ((uint32_t)len > (uint32_t)kMaxStreamLen) { store_refusal(a, s, lane, 4); return; }
     if (len < kSync) { store_refusal(a, s, lane, 1); return; }   // ref:323-325
     const int16_t* xs = a.samples + a.stream_offset[s];
     uint8_t* out_row = a.out_bytes + (int64_t)s * a.out_stride;
@@ -333,8 +344,10 @@ __global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) 
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = blockIdx.x * WPB + wave;
-    if (s >= a.n_streams) return;
+    const int w = blockIdx.x * WPB + wave;
+    if (w >= a.n_streams) return;
+    // grouped dispatch: the launch covers a LIST of streams (all of this kernel's rate); one scalar load
+    const int s = a.stream_index ? __builtin_amdgcn_readfirstlane(a.stream_index[w]) : w;
     process_uniform_stream<BF, FLAGS, BIG>(a, s, lds_all + wave * kFastWaveLdsProduct, lane);
 }
 

@@ -25,7 +25,11 @@ __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
     const int s = (int)(w / a.max_blocks);
     if (s >= a.n_streams) return;
     const int b = (int)(w - (int64_t)s * a.max_blocks);
-    const int32_t nb = a.stream_len[s] / kListenBlock;
+    const int32_t len = a.stream_len[s];
+    // a capture longer than the caller's own bound (max_stream_len, which sized the workspace rows and the
+    // grid) or negative is refused, not read: device-side lengths are data the host never saw
+    if ((uint32_t)len > (uint32_t)a.max_len) return;
+    const int32_t nb = len / kListenBlock;
     if (b >= nb) return;
     const int16_t* src = a.samples + a.stream_offset[s] + (int64_t)b * kListenBlock;
     uint32_t acc = 0;
@@ -53,7 +57,13 @@ __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
 __global__ __launch_bounds__(256) void gate_scan_kernel(GateArgs a) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.n_streams) return;
-    const int32_t nb = a.stream_len[s] / kListenBlock;
+    const int32_t len = a.stream_len[s];
+    if ((uint32_t)len > (uint32_t)a.max_len) {               // refused capture: out_n_bursts = -1, no burst written
+        a.out_n_bursts[s] = -1;
+        a.out_open_end[s] = 0;
+        return;
+    }
+    const int32_t nb = len / kListenBlock;
     const int32_t* amp = a.block_amp + (int64_t)s * a.max_blocks;
     int32_t* bs = a.out_burst_start + (int64_t)s * a.max_bursts;
     int32_t* bl = a.out_burst_len + (int64_t)s * a.max_bursts;

@@ -25,7 +25,14 @@ struct DemodArgs {
     int32_t* out_margins = nullptr;               // [n, margin_stride] space_diff - mark_diff per symbol
     int32_t margin_stride = 0;
     int32_t uniform_bit_frames = 0;               // the one bit_frames of a uniform launch (afsk_demod_batch_uniform)
+    // grouped dispatch (afsk_demod_batch_grouped): wave w of a uniform launch decodes stream stream_index[w]
+    // (n_streams = entries of the list); every per-stream array, inputs and outputs, is addressed by that
+    // stream number.  null = wave w decodes stream w.
+    const int32_t* stream_index = nullptr;
 };
+
+// Longest stream the kernels address (32-bit byte offsets into a stream): AFSK_MAX_STREAM_LEN of the C-ABI.
+constexpr int32_t kMaxStreamLen = (1 << 30) - (1 << 15);
 
 struct ModulateArgs {
     const uint8_t* payload;
@@ -39,6 +46,7 @@ struct ModulateArgs {
     int32_t wav_quirk;
     int16_t* samples;
     int32_t chunks;   // blocks per stream (set by the launcher)
+    int32_t max_len;  // the caller's bound of stream_len[] (set by the launcher): longer / negative entries are skipped
 };
 
 struct NoiseArgs {
@@ -50,6 +58,7 @@ struct NoiseArgs {
     uint32_t seed;
     uint32_t stream_idx_base;
     int32_t chunks;
+    int32_t max_len;  // as ModulateArgs::max_len
 };
 
 struct GateArgs {
@@ -59,6 +68,7 @@ struct GateArgs {
     int32_t amp_start;
     int32_t amp_end;
     int32_t n_streams;
+    int32_t max_len;        // the caller's bound of stream_len[]: longer / negative entries are refused
     int32_t max_blocks;     // workspace row length = max_stream_len / 2048
     int32_t max_bursts;
     int32_t* block_amp;     // [n_streams, max_blocks]
@@ -72,6 +82,9 @@ hipError_t launch_gate(const GateArgs& a, hipStream_t stream);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
 // one bit_frames (a.uniform_bit_frames, host-validated) for every stream of the launch
 hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream);
+// status `status` (and empty outputs) for the `count` streams listed in stream_index (grouped dispatch:
+// the streams whose host-side bit_frames is invalid)
+hipError_t launch_refuse(const DemodArgs& a, int32_t status, hipStream_t stream);
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);
 hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream);
 

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(THREADS) void modulate_kernel_t(ModulateArgs a) {
     __shared__ uint32_t qbits[q_words(kModChunk)];
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
+    // a device-side length outside [0, max_stream_len] (the caller's own bound, which sized the grid) is
+    // refused: nothing is written for that stream
+    if ((uint32_t)a.stream_len[s] > (uint32_t)a.max_len) return;
     const uint32_t len = (uint32_t)a.stream_len[s];
     const uint32_t base = (uint32_t)chunk * kModChunk;
     if (base >= len) return;                                   // block-uniform
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256) void noise_kernel(NoiseArgs a) {
     const int s = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x - s * a.chunks;
     const int32_t len = a.stream_len[s];
+    if ((uint32_t)len > (uint32_t)a.max_len) return;           // refused like modulate_kernel_t: stream untouched
     const int64_t p0 = ((int64_t)chunk * blockDim.x + threadIdx.x) * 8;
     if (p0 >= len) return;
     const int64_t scale = a.scale_q24[s];
@@ -263,6 +267,7 @@ hipError_t launch_modulate_t(ModulateArgs a, int32_t max_len, hipStream_t stream
     if (a.n_streams <= 0 || max_len <= 0) return hipSuccess;
     const int per_block = mod_chunk(ITERS, THREADS);
     a.chunks = (max_len + per_block - 1) / per_block;
+    a.max_len = max_len;
     const int64_t blocks = (int64_t)a.chunks * a.n_streams;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((modulate_kernel_t<ITERS, THREADS>), dim3((uint32_t)blocks), dim3(THREADS), 0, stream, a);
@@ -277,6 +282,7 @@ hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream) {
     if (a.n_streams <= 0 || max_len <= 0) return hipSuccess;
     const int per_block = 256 * 8;
     a.chunks = (max_len + per_block - 1) / per_block;
+    a.max_len = max_len;
     const int64_t blocks = (int64_t)a.chunks * a.n_streams;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(noise_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);

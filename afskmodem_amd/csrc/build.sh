@@ -11,6 +11,12 @@ OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 # bit_frames values with a compile-time geometry = AFSK_FAST_BF_LIST + AFSK_GP_BF_LIST in afsk_demod_impl.h; 0 = run-time geometry
 UNIFORM_BF=$(sed -n 's/^#define AFSK_\(FAST\|GP\)_BF_LIST(X)//p' afsk_demod_impl.h | tr -d 'X()' | tr '\n' ' ')
+WANT=$(sed -n 's/^static_assert(kUniformBfCount == \([0-9]*\),.*/\1/p' afsk_demod_impl.h)
+HAVE=$(echo $UNIFORM_BF | wc -w)
+if [ -z "$WANT" ] || [ "$HAVE" -ne "$WANT" ]; then
+  echo "build.sh: scraped $HAVE bit_frames values from afsk_demod_impl.h, the header says ${WANT:-?} (kUniformBfCount): the AFSK_*_BF_LIST macros must stay on one line each" >&2
+  exit 1
+fi
 {
   # longest jobs first
   for f in afsk_demod_small afsk_demod_big; do echo "$f.o $f.hip"; done

@@ -288,8 +288,13 @@ class Shard:
             copies = min(copies, 8)
         for _ in range(copies - 1):
             self.inputs.append(x.clone())
-        # one baud rate in the whole shard -> the Receiver-shaped uniform entry (bit_frames by value)
+        # one baud rate in the whole shard -> the Receiver-shaped uniform entry (bit_frames by value); several ->
+        # the rate-grouped dispatch (the host knows every stream's rate: one uniform kernel per rate, concurrently);
+        # --entry mixed forces the per-stream kernel (bit_frames[] in device memory) for A/B runs
         self.uniform_bf = int(self.bf_h[0]) if (len(set(bauds)) == 1 and ctx.args.entry != "mixed") else None
+        self.plan = None
+        if self.uniform_bf is None and ctx.args.entry != "mixed":
+            self.plan = batch.GroupPlan(self.bf_h, ctx.dev)
         self.stride = batch.out_stride_for(STREAM_LEN, int(self.bf_h.min()))
         _, self.flat_sz = batch.flat_layout(n_local, self.stride)
         torch.cuda.synchronize()
@@ -374,6 +379,12 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     if sh.uniform_bf is not None:
         fn = ctx.lib.afsk_demod_batch_uniform
         slot_args = [[(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.uniform_bf, 14000, n_local,
+                       o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(),
+                       o.clock_idx.data_ptr(), o.term_frame.data_ptr(), o.status.data_ptr(), None, None, 0, sptr)
+                      for o in slots] for x in sh.inputs]
+    elif sh.plan is not None:
+        fn = ctx.lib.afsk_demod_batch_grouped
+        slot_args = [[(sh.plan.handle, x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), 14000,
                        o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(),
                        o.clock_idx.data_ptr(), o.term_frame.data_ptr(), o.status.data_ptr(), None, None, 0, sptr)
                       for o in slots] for x in sh.inputs]
@@ -518,7 +529,9 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
     rec = {
         "workload": sh.desc,
         "streams_per_gpu": n_local,
-        "entry": "afsk_demod_batch_uniform" if sh.uniform_bf is not None else "afsk_demod_batch",
+        "entry": ("afsk_demod_batch_uniform" if sh.uniform_bf is not None else
+                  "afsk_demod_batch_grouped" if sh.plan is not None else "afsk_demod_batch"),
+        "launches_per_step": 1 if sh.plan is None else len(sh.plan.groups()),
         "steps": steps, "warmup": warmup, "preroll_launches": preroll_launches,
         "value": round(samples_per_step * steps / elapsed / 1e6, 1),            # wall clock of the median region, fences included
         "value_event_time": round(samples_per_step * steps * n_regions / (event_ms * 1e-3) / 1e6, 1),   # HIP events, all regions
@@ -641,7 +654,7 @@ def ber_curve(ctx: Ctx, sh: Shard, sample: int, n_threads: int) -> list:
     ns = min(sample, sh.n_local)
     for snr in BER_SNRS:
         sh.regenerate(float(snr), seed=1000 + snr)
-        res = batch.demod_batch(sh.inputs[0], sh.off, sh.ln, sh.bf, 14000, out_stride=sh.stride)
+        res = batch.demod_batch(sh.inputs[0], sh.off, sh.ln, sh.uniform_bf if sh.uniform_bf is not None else sh.bf, 14000, out_stride=sh.stride)
         torch.cuda.synchronize()
         got = res.cpu()
         ber, bad = ber_of(got.nbytes, got.bytes, sh.payload_h, plen)
@@ -1173,7 +1186,8 @@ def main() -> None:
     ap.add_argument("--min-region-ms", type=float, default=50.0,
                     help="repeat the K-step timed region until the regions add up to this (0 = exactly one region)")
     ap.add_argument("--entry", default="auto", choices=["auto", "mixed"],
-                    help="auto = one-rate shards use afsk_demod_batch_uniform; mixed = always the per-stream entry (A/B)")
+                    help="auto = one-rate shards use afsk_demod_batch_uniform, several rates afsk_demod_batch_grouped; "
+                         "mixed = always the per-stream entry afsk_demod_batch (A/B)")
     ap.add_argument("--next-reps", type=int, default=20, help="timed launches of the f1 / f2 sub-records")
     ap.add_argument("--wav-files", type=int, default=4096, help="files of the f3_wav_ingest sub-record")
     ap.add_argument("--sub-steps", type=int, default=0, help="timed steps of every sub-record (0 = 20 / 200)")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AFSK_ABI_VERSION 1
+#define AFSK_ABI_VERSION 2 /* 2: afsk_group_plan_* / afsk_demod_batch_grouped, AFSK_ST_BAD_LENGTH */
 
 /* return codes */
 #define AFSK_OK 0
@@ -44,6 +44,9 @@ extern "C" {
 #define AFSK_ST_TOO_SHORT 1 /* len < 4096 [__recoverClockIndex -> -1 -> "" , :323-325] */
 #define AFSK_ST_NO_DATA 2   /* no terminator / zero bits [bits == "" -> b"", :422-424]  */
 #define AFSK_ST_INVALID_BAUD 3 /* bit_frames[s] rejected (host wrappers raise before launch) */
+#define AFSK_ST_BAD_LENGTH 4 /* stream_len[s] < 0 or > AFSK_MAX_STREAM_LEN: refused by the kernel before any
+                                sample is addressed (the device entries never see the length array on the
+                                host; the host entries reject such a batch with AFSK_E_INVALID_ARG) */
 
 /* Fixed constants of the reference that the kernels compile in. */
 #define AFSK_SAMPLE_RATE 48000 /* :69,71,187,233,260,277 */
@@ -68,7 +71,8 @@ int afsk_sync(void *hip_stream);
  *
  *  samples        int16 mono 48 kHz, all streams in one allocation
  *  stream_offset  [n] first sample of stream s, in samples from `samples`
- *  stream_len     [n] length of stream s in samples (0 ... AFSK_MAX_STREAM_LEN)
+ *  stream_len     [n] length of stream s in samples (0 ... AFSK_MAX_STREAM_LEN; anything else:
+ *                 status AFSK_ST_BAD_LENGTH for that stream, its neighbours are unaffected)
  *  bit_frames     [n] 48000 / baud of stream s (Receiver.__init__ :277);
  *                 must be a multiple of 4 with 2*bit_frames < 4096
  *  amp_end_threshold  Receiver(amp_end_threshold=...) (:276), squelch of :375
@@ -132,14 +136,48 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
                              void *hip_stream);
 
 /*
+ * Rate-grouped dispatch of a MIXED-baud batch whose bit_frames the HOST can see (a list of Receivers of
+ * different baud rates, each with its own streams: one baud rate per Receiver, :275-284; streams are
+ * independent, :354-381).  The plan buckets the streams by bit_frames once; afsk_demod_batch_grouped then
+ * launches, per rate, the kernel of afsk_demod_batch_uniform compiled for exactly that symbol geometry over
+ * the rate's list of streams, the launches running concurrently on the plan's side streams, forked from
+ * and joined back into hip_stream with events only: no host synchronisation, asynchronous like every
+ * device entry, and a stream capture of hip_stream records it as a fork / join.  Outputs land at the
+ * ORIGINAL stream numbers, bit for bit what afsk_demod_batch_ex writes for the same bit_frames[] (a stream
+ * with an invalid bit_frames gets status AFSK_ST_INVALID_BAUD).  afsk_demod_batch (bit_frames[] in device
+ * memory, one launch, every geometry behind a per-stream switch) stays the entry for rates only the device
+ * knows.
+ *
+ *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates the device index list (n int32) on
+ *                           the current device, copies it (synchronous), creates up to 7 side streams.
+ *  afsk_group_plan_info     n_streams, number of launches, and per launch (first `cap` of them) its
+ *                           bit_frames (0 = the refused streams) and stream count; any pointer may be NULL
+ *  afsk_demod_batch_grouped every array as afsk_demod_batch_ex, indexed by the original stream number;
+ *                           n_streams is the plan's.  Calls sharing one plan must be issued from one thread
+ *                           at a time (they share the plan's events); they may be queued back to back.
+ *  afsk_group_plan_destroy  after the launches that use the plan have completed (NULL is fine)
+ */
+typedef struct afsk_group_plan afsk_group_plan;
+int afsk_group_plan_create(const int32_t *bit_frames_host, int32_t n_streams, afsk_group_plan **out_plan);
+int afsk_group_plan_info(const afsk_group_plan *plan, int32_t *out_n_streams, int32_t *out_n_groups,
+                         int32_t *out_group_bit_frames, int32_t *out_group_count, int32_t cap);
+int afsk_group_plan_destroy(afsk_group_plan *plan);
+int afsk_demod_batch_grouped(const afsk_group_plan *plan, const int16_t *samples,
+                             const int64_t *stream_offset, const int32_t *stream_len,
+                             int32_t amp_end_threshold, uint8_t *out_bytes, int32_t out_stride,
+                             int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
+                             int32_t *out_term_frame, int32_t *out_status, int32_t *out_corrected,
+                             int32_t *out_margins, int32_t margin_stride, void *hip_stream);
+
+/*
  * Same operation on HOST buffers: allocates device scratch, copies in, runs the
  * HIP kernel, copies out, synchronises.  This is the PCIe-inclusive convenience
  * path a single Receiver.load() uses; it is not the benchmarked entry.
  * Both host entries work on a private NON-BLOCKING HIP stream of the calling thread (never the
  * NULL stream): they do not synchronise with the caller's own streams or with calls made by
  * other threads, and may be called concurrently (the reference's Receivers are independent
- * objects, afskmodem.py:275-284).  When every bit_frames[s] holds the same value (the host can see
- * that here) they launch the uniform kernel of afsk_demod_batch_uniform.  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
+ * objects, afskmodem.py:275-284).  The host can see bit_frames[] here: one value -> the uniform kernel of
+ * afsk_demod_batch_uniform, several -> the rate-grouped dispatch of afsk_demod_batch_grouped.  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
  */
 int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           const int64_t *stream_offset, const int32_t *stream_len,
@@ -242,7 +280,8 @@ int afsk_wav_ingest(const char *const *paths, int32_t n_files, const int64_t *sl
  *               Waveforms accept, :69-70/:81-82, gives one); any other value yields an
  *               all-zero stream (device arrays are not validated on the host)
  *  ts_cycles    [n] int(baud * training_time / 2)   (:438)
- *  max_stream_len  host-side upper bound of stream_len[] (sizes the grid)
+ *  max_stream_len  host-side upper bound of stream_len[] (sizes the grid); a stream whose device-side
+ *               stream_len[s] is negative or above it is skipped (nothing written for it)
  */
 int afsk_modulate_batch(const uint8_t *payload, int32_t payload_stride,
                         const int32_t *payload_len, const int32_t *bit_frames,
@@ -258,7 +297,9 @@ int afsk_modulate_batch(const uint8_t *payload, int32_t payload_stride,
  * blocks up to and including the first one with getAmplitude < amp_end_threshold (:316).
  * Only whole blocks of the capture are considered (no timeout: the call scans to the end).
  *
- *  max_stream_len   host-side upper bound of stream_len[]; max_blocks = max_stream_len / 2048
+ *  max_stream_len   host-side upper bound of stream_len[]; max_blocks = max_stream_len / 2048.  A capture
+ *                   whose device-side stream_len[s] is negative or above it is refused:
+ *                   out_n_bursts[s] = -1, no sample of it is read
  *  block_amp        workspace AND output, int32 [n, max_blocks]: int(sum|x| / 2048) per block
  *  out_n_bursts     [n] bursts found (<= max_bursts)
  *  out_burst_start  [n, max_bursts] first sample of burst k, relative to the stream start

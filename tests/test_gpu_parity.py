@@ -30,18 +30,22 @@ def torch_cuda():
 REAL_DEMOD_BATCH = batch.demod_batch
 
 
-@pytest.fixture(autouse=True, params=["mixed", "uniform"])
+@pytest.fixture(autouse=True, params=["mixed", "uniform", "grouped"])
 def entry(request, monkeypatch):
-    """Every test of this file runs twice: once with every device launch forced through the
-    per-stream entry (afsk_demod_batch / _ex: the mixed-baud kernel) and once through the
-    Receiver-shaped afsk_demod_batch_uniform (one kernel per bit_frames).  A batch with several
-    baud rates is, in the second run, split into one uniform launch per rate and scattered back
-    into one result -- so every parity case below pins both kernel families.  (Host entries pick the
-    uniform kernel themselves when their bit_frames array holds one value.)"""
+    """Every test of this file runs three times: with every device launch forced through the
+    per-stream entry (afsk_demod_batch / _ex: the mixed-baud kernel), through the
+    Receiver-shaped afsk_demod_batch_uniform (one kernel per bit_frames), and through the rate-grouped
+    dispatch afsk_demod_batch_grouped (the same uniform kernels over per-rate stream lists, concurrently,
+    outputs at the original stream numbers -- also for one-rate batches, so the index list is exercised
+    by every case).  A batch with several baud rates is, in the second run, split BY THE TEST into one
+    uniform launch per rate and scattered back into one result -- so every parity case below pins both
+    kernel families and both ways of reaching the second.  (Host entries pick the uniform kernel or the
+    grouped dispatch themselves, from their bit_frames array.)"""
     mode = request.param
 
     def wrapped(samples, stream_offset, stream_len, bit_frames, amp_end_threshold=14000, out=None,
-                out_stride=None, stream=None, validate=True, diagnostics=False, margin_stride=None, entry="auto"):
+                out_stride=None, stream=None, validate=True, diagnostics=False, margin_stride=None, entry="auto",
+                plan=None):
         import torch
         n = int(stream_offset.numel())
         kw = dict(stream=stream, diagnostics=diagnostics, margin_stride=margin_stride)
@@ -52,6 +56,9 @@ def entry(request, monkeypatch):
                 else np.broadcast_to(np.asarray(bit_frames, np.int32), (n,)))
         if validate and n:
             batch.validate_bit_frames(bf_h)
+        if mode == "grouped":
+            return REAL_DEMOD_BATCH(samples, stream_offset, stream_len, np.ascontiguousarray(bf_h), amp_end_threshold,
+                                    out=out, out_stride=out_stride, validate=False, entry="grouped", **kw)
         values = sorted(set(int(v) for v in bf_h))
         if len(values) <= 1:
             return REAL_DEMOD_BATCH(samples, stream_offset, stream_len, values[0] if values else 40,
@@ -876,7 +883,16 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
     torch = torch_cuda
     stride = 64
     threads = os.cpu_count() or 16
-    if entry == "mixed":
+    if entry == "grouped":
+        # two rates (a compile-time fast geometry and a general-piece one), n streams EACH, interleaved: both
+        # launches of the grouped dispatch are large ones (hint, and at 8256 warming) reading their streams
+        # through the index list, concurrently on two HIP streams
+        flat, off, ln, bf = large_launch_streams(2 * n, (1200, 375), 4242)
+        got = device_demod(torch, flat, off, ln, bf, stride=stride)
+        want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=threads)
+        assert_same(got, want, "grouped large launch")
+        assert (got.nbytes > 0).sum() > n // 2
+    if entry in ("mixed", "grouped"):
         flat, off, ln, bf = large_launch_streams(n, LARGE_LAUNCH_BAUDS, 99)
         got = device_demod(torch, flat, off, ln, bf, stride=stride)
         want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=threads)
@@ -922,7 +938,11 @@ def test_uniform_runtime_geometry_large_launch(torch_cuda, entry, n):
         q = np.where(np.arange(n) % 3 == 0, synth.snr_to_scale_q24(8.0), synth.snr_to_scale_q24(40.0)).astype(np.int32)
         batch.add_noise_batch(x, d_off, d_ln, total, q, seed=bf_v)
         stride = 16
-        res = REAL_DEMOD_BATCH(x, d_off, d_ln, bf_v, 14000, out_stride=stride, validate=False, entry="uniform")
+        if entry == "grouped":
+            res = REAL_DEMOD_BATCH(x, d_off, d_ln, np.full(n, bf_v, np.int32), 14000, out_stride=stride, validate=False,
+                                   entry="grouped")
+        else:
+            res = REAL_DEMOD_BATCH(x, d_off, d_ln, bf_v, 14000, out_stride=stride, validate=False, entry="uniform")
         torch.cuda.synchronize()
         want = O.demod_batch(x.cpu().numpy(), off, ln, np.full(n, bf_v, np.int32), 14000, out_stride=stride,
                              n_threads=os.cpu_count() or 16)
@@ -1175,11 +1195,15 @@ def test_launch_is_graph_capture_safe(torch_cuda, entry):
     """The C-ABI launch path does no allocation / synchronisation, so a sequence of demod
     launches can be captured into a HIP graph and replayed (guideline: no hipMalloc / sync in
     the launch function).  Mixed entry: a three-rate batch with bit_frames on the device; uniform
-    entry: one rate, bit_frames by value."""
+    entry: one rate, bit_frames by value; grouped entry: the three-rate batch with a plan built BEFORE the
+    capture (the first, uncaptured call builds and caches it) -- the capture records the fork onto the plan's
+    side streams, three concurrent launches and the join."""
     torch = torch_cuda
-    b = synth_batch(torch, 256, (300, 1200, 2400) if entry == "mixed" else (2400,), seed=99)
+    b = synth_batch(torch, 256, (2400,) if entry == "uniform" else (300, 1200, 2400), seed=99)
     if entry == "uniform":
         b["bf"] = 20
+    if entry == "grouped":
+        b["bf"] = b["h_bf"]                       # host array: nothing is read back from the device inside the capture
     stride = batch.out_stride_for(48000, 20)
     ref_out = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride).cpu()
     outs = [batch.alloc_result(256, stride, "cuda:0") for _ in range(3)]
@@ -1208,7 +1232,7 @@ def test_side_stream_launch_with_in_call_allocations(torch_cuda, entry):
     fill so that a missing dependency would let the zero fill land after the kernel's stores.  Calls the
     real entry (not the per-rate splitter of the `entry` fixture, which scatters on the current stream)."""
     torch = torch_cuda
-    bauds = (300, 1200, 2400) if entry == "mixed" else (1200,)
+    bauds = (1200,) if entry == "uniform" else (300, 1200, 2400)
     b = synth_batch(torch, 192, bauds, seed=314)
     bf_h = b["bf"].cpu().numpy()
     stride = batch.out_stride_for(48000, 20)
@@ -1225,3 +1249,191 @@ def test_side_stream_launch_with_in_call_allocations(torch_cuda, entry):
         side.synchronize()
         torch.cuda.synchronize()
         assert_same(res.cpu(), want, f"side stream rep {rep}")
+
+
+# ------------------------------------------------------------------ round 4: device-side guards, config #4 at full size, grouped dispatch
+
+
+def test_device_side_lengths_are_guarded_in_the_kernels(torch_cuda):
+    """The device entries never see stream_len[] on the host: a NEGATIVE entry or one above
+    AFSK_MAX_STREAM_LEN is refused by the kernel itself -- status AFSK_ST_BAD_LENGTH, empty record, no
+    sample addressed -- inside a launch of 8256 streams (hint + warming armed) whose other streams decode
+    bit-exactly as if the poisoned ones were not there.  Same for the gate (out_n_bursts = -1) and the
+    modulator / noise generator (stream left untouched), whose bound is the caller's max_stream_len."""
+    torch = torch_cuda
+    dev = "cuda:0"
+    n = 8256
+    flat, off, ln, bf = large_launch_streams(n, (1200, 300, 2400, 375), 777)
+    poison = {5: -1, 64: -2 ** 31, 4097: _native.MAX_STREAM_LEN + 1, 8191: 2 ** 31 - 1, 8255: -4096, 100: -48000}
+    ln_p = ln.copy()
+    for s_i, v in poison.items():
+        ln_p[s_i] = v
+    got = device_demod(torch, flat, off, ln_p, bf, stride=64)
+    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=64, n_threads=os.cpu_count() or 16)
+    bad = np.array(sorted(poison))
+    good = np.setdiff1d(np.arange(n), bad)
+    for f in FIELDS:
+        assert np.array_equal(getattr(got, f)[good], want[f][good]), f
+    m = np.arange(64)[None, :] < np.minimum(want["nbytes"][good], 64)[:, None]
+    assert not ((got.bytes[good] != want["bytes"][good, :64]) & m).any()
+    assert (got.status[bad] == _native.ST_BAD_LENGTH).all()
+    assert (got.nbytes[bad] == 0).all() and (got.nbits[bad] == 0).all()
+    assert (got.clock_idx[bad] == -1).all() and (got.term_frame[bad] == -1).all()
+    # AFSK_MAX_STREAM_LEN itself is a legal length (test_maximum_stream_length decodes one); 0 is "too short"
+    ln_z = ln.copy()
+    ln_z[7] = 0
+    assert device_demod(torch, flat, off, ln_z, bf, stride=64).status[7] == _native.ST_TOO_SHORT
+
+    # gate: bound = max_stream_len of the call
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    caps = 64
+    L = 20480
+    rng = np.random.default_rng(12)
+    x = (rng.integers(-30000, 30000, caps * L).astype(np.int16))
+    g_ln = np.full(caps, L, np.int32)
+    g_ln[[3, 17, 40]] = (-1, L + 1, 2 ** 31 - 1)
+    g_off = np.arange(caps, dtype=np.int64) * L
+    g = batch.gate_batch(t(x), t(g_off), t(g_ln), L, 18000, 14000, 4)
+    torch.cuda.synchronize()
+    nb = g.n_bursts.cpu().numpy()
+    assert list(nb[[3, 17, 40]]) == [-1, -1, -1]
+    for i in (0, 2, 4, 16, 18, 63):
+        bursts, oe = O.gate_stream(x[i * L: (i + 1) * L], 18000, 14000, 4)
+        assert int(nb[i]) == len(bursts) and int(g.open_end[i].item()) == oe
+    owner, _, _ = g.burst_streams(t(g_off))
+    assert not set(owner.cpu().numpy().tolist()) & {3, 17, 40}
+
+    # modulator + noise: a poisoned stream keeps whatever the buffer held
+    ns = 8
+    m_ln = np.full(ns, 12000, np.int32)
+    m_ln[[2, 5]] = (-7, 12001)
+    m_off = np.arange(ns, dtype=np.int64) * 12000
+    buf = torch.full((ns * 12000,), 1234, dtype=torch.int16, device=dev)
+    payload = synth.payload_bytes(3, 0, ns, 4)
+    batch.modulate_batch(t(payload), t(np.full(ns, 4, np.int32)), t(np.full(ns, 40, np.int32)),
+                         t(np.full(ns, 30, np.int32)), t(m_off), t(m_ln), 12000, buf, True)
+    batch.add_noise_batch(buf, t(m_off), t(m_ln), 12000, np.full(ns, synth.snr_to_scale_q24(20.0), np.int32), seed=1)
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy().reshape(ns, 12000)
+    assert (h[2] == 1234).all() and (h[5] == 1234).all()
+    ok_ln = np.where(m_ln == 12000, 12000, 0).astype(np.int32)
+    ref = O.modulate_batch(payload, np.full(ns, 4, np.int32), np.full(ns, 40, np.int32), np.full(ns, 30, np.int32),
+                           m_off, ok_ln, ns * 12000, True).reshape(ns, 12000)
+    for i in (0, 1, 3, 4, 6, 7):
+        assert np.array_equal(h[i], O.add_noise(ref[i], 1, i, synth.snr_to_scale_q24(20.0))), i
+
+
+def test_full_size_config4_noise_sweep(torch_cuda):
+    """BASELINE config #4 AT FULL SIZE: 65536 x 1 s @1200 baud at each SNR of the sweep {30, 25, 20, 15, 10, 7, 5} dB
+    (sigma = 32767.5 / 10^(SNR/20)), all streams on the GPU; the CPU oracle decodes 1024 streams per
+    SNR -- every output field -- so BER(GPU) == BER(CPU) on that sample; over ALL 65536 streams BER is exactly 0
+    for SNR >= 10 dB (round trip to the modulated payloads), and the squelch over-read of ref:372-378 (noise
+    holding the amplitude above amp_end past the last data symbol: more than 14 * 34 coded bits) appears at
+    7 dB and below."""
+    torch = torch_cuda
+    n, plen, sample = 65536, 34, 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < 10 * 2 ** 30:
+        pytest.skip("needs ~7 GB of free HBM")
+    b = synth_batch(torch, n, (1200,), seed=4400)
+    clean = b["samples"].clone()
+    stride = batch.out_stride_for(48000, 40)
+    out = batch.alloc_result(n, stride, "cuda:0")
+    threads = os.cpu_count() or 16
+    pick = np.arange(0, n, n // sample)                      # every 64th stream
+    d_pick = torch.from_numpy(pick).to("cuda:0")
+    col = np.arange(plen)[None, :]
+
+    def ber(nbytes, rows, payload):
+        nb = nbytes.astype(np.int64)
+        m = np.minimum(nb, plen)
+        bits = np.unpackbits((rows[:, :plen] ^ payload[:, :plen]) * (col < m[:, None]).astype(np.uint8), axis=1).sum(axis=1)
+        errs = bits + 8 * np.abs(nb - plen)
+        return float(errs.sum()) / (len(nb) * plen * 8)
+
+    over = {}
+    for snr in (30, 25, 20, 15, 10, 7, 5):
+        b["samples"].copy_(clean)
+        q = np.full(n, synth.snr_to_scale_q24(float(snr)), np.int32)
+        batch.add_noise_batch(b["samples"], b["off"], b["ln"], 48000, q, seed=5000 + snr, stream_idx_base=0)
+        batch.demod_batch(b["samples"], b["off"], b["ln"], 40, 14000, out=out)
+        torch.cuda.synchronize()
+        got = out.cpu()
+        xs = b["samples"].view(n, 48000)[d_pick].cpu().numpy().reshape(-1)
+        want = O.demod_batch(xs, np.arange(sample, dtype=np.int64) * 48000, np.full(sample, 48000, np.int32),
+                             np.full(sample, 40, np.int32), 14000, out_stride=stride, n_threads=threads)
+        sub = batch.HostDemodResult(got.bytes[pick], *(getattr(got, f)[pick] for f in FIELDS))
+        assert_same(sub, want, f"config4 {snr} dB")
+        assert ber(sub.nbytes, sub.bytes, b["payload"][pick]) == ber(want["nbytes"], want["bytes"], b["payload"][pick])
+        all_ber = ber(got.nbytes, got.bytes, b["payload"])
+        over[snr] = int((got.nbits > 14 * plen).sum())
+        if snr >= 10:
+            assert all_ber == 0.0, (snr, all_ber)
+            assert (got.nbytes == plen).all() and np.array_equal(got.bytes[:, :plen], b["payload"][:, :plen])
+        else:
+            assert all_ber < 1e-3, (snr, all_ber)
+    assert over[30] == 0 and over[10] == 0
+    assert over[7] > 0 and over[5] > over[7], over
+    del b, clean, out
+    torch.cuda.empty_cache()
+
+
+def test_grouped_dispatch_plan_api(torch_cuda, entry):
+    """afsk_group_plan_* / afsk_demod_batch_grouped directly (not through the `entry` fixture): bucket order and
+    counts, a plan reused across launches and thresholds, status 3 for streams whose host-side bit_frames is
+    invalid (what the per-stream kernel writes for them), soft outputs at the original stream numbers, a
+    plan/batch mismatch refused, and equality with the per-stream entry on the same batch, field by field."""
+    if entry != "grouped":
+        pytest.skip("entry-independent: runs once")
+    torch = torch_cuda
+    n = 600
+    b = synth_batch(torch, n, (1200, 375, 300, 96, 2400, 160), seed=606, snr_db=np.where(np.arange(n) % 4 == 0, 7.0, 40.0))
+    bf_h = b["h_bf"].copy()
+    bf_h[[11, 222]] = (42, 0)                              # not a multiple of 4 / zero: refused, status 3
+    bf_h[333] = 2048                                       # 2 * bf >= 4096
+    plan = batch.GroupPlan(bf_h)
+    groups = plan.groups()
+    assert sum(c for _, c in groups) == n and groups[-1] == (0, 3)
+    counts = [c for _, c in groups[:-1]]
+    assert counts == sorted(counts, reverse=True) and {g for g, _ in groups[:-1]} == {40, 128, 160, 500, 20, 300}
+    stride = batch.out_stride_for(48000, 20)
+    ms = 48000 // 20
+    for amp_end in (14000, 9000.5):
+        got = REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], None, amp_end, out_stride=stride, plan=plan,
+                               diagnostics=True, margin_stride=ms)
+        ref = REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], torch.from_numpy(bf_h).to("cuda:0"), amp_end,
+                               out_stride=stride, validate=False, entry="mixed", diagnostics=True, margin_stride=ms)
+        torch.cuda.synchronize()
+        g, r = got.cpu(), ref.cpu()
+        for f in FIELDS:
+            assert np.array_equal(getattr(g, f), getattr(r, f)), (f, amp_end)
+        assert (g.status[[11, 222, 333]] == _native.ST_INVALID_BAUD).all()
+        m = np.arange(stride)[None, :] < np.minimum(r.nbytes, stride)[:, None]
+        assert not ((g.bytes != r.bytes) & m).any()
+        assert torch.equal(got.corrected, ref.corrected)
+        ok = np.setdiff1d(np.arange(n), [11, 222, 333])
+        nsym = got.symbols_demodulated(torch.from_numpy(np.maximum(bf_h, 4)).to("cuda:0")).cpu().numpy()
+        gm, rm = got.margins.cpu().numpy(), ref.margins.cpu().numpy()
+        for s_i in ok[::7]:
+            k = min(int(nsym[s_i]), ms)
+            assert np.array_equal(gm[s_i, :k], rm[s_i, :k]), s_i
+    with pytest.raises(ValueError, match="plan covers"):
+        REAL_DEMOD_BATCH(b["samples"], b["off"][:10].contiguous(), b["ln"][:10].contiguous(), None, 14000,
+                         out_stride=stride, plan=plan)
+    with pytest.raises(ValueError, match="1 or 600"):
+        REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], [40, 40, 40], 14000, out_stride=stride)
+    plan.close()
+    with pytest.raises(ValueError, match="closed"):
+        REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], None, 14000, out_stride=stride, plan=plan)
+    # auto: a host list with several rates takes the grouped dispatch, an all-equal one the uniform kernel
+    auto = REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], [int(v) for v in b["h_bf"]], 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    want = O.demod_batch(b["samples"].cpu().numpy(), b["h_off"], b["h_ln"], b["h_bf"], 14000, out_stride=stride, n_threads=16)
+    assert_same(auto.cpu(), want, "auto -> grouped")
+    # host entries with several rates: the same dispatch behind afsk_demod_batch_host / afsk_demod_streams_host
+    h = b["samples"].cpu().numpy()
+    flat = batch.demod_host_flat(h, b["h_off"], b["h_ln"], b["h_bf"], 14000, stride)
+    assert_same(flat, want, "host flat -> grouped")
+    arrs = batch.demod_host_arrays([h[i * 48000: (i + 1) * 48000] for i in range(n)], b["h_bf"], 14000)
+    for f in FIELDS:
+        assert np.array_equal(getattr(arrs, f), want[f]), f

@@ -148,7 +148,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.afsk_version() == 1
+    assert lib.afsk_version() == 2
     assert int(re.search(r"#define AFSK_ABI_VERSION (\d+)", hdr).group(1)) == lib.afsk_version()
 
 
@@ -239,6 +239,36 @@ def test_cabi_argument_checks_new_entries():
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, -1, *u_tail) == _native.E_INVALID_ARG
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 0, *u_tail) == 0
     assert lib.afsk_demod_batch_uniform(None, None, None, 40, 14000, 4, *u_tail) == _native.E_INVALID_ARG   # null pointers
+
+
+def test_group_plan_argument_checks_need_no_gpu():
+    """afsk_group_plan_* / afsk_demod_batch_grouped: argument validation comes before any device call; without a
+    GPU plan creation fails loudly (AFSK_E_NO_DEVICE), never with a CPU stand-in."""
+    lib = _native.lib()
+    h = ctypes.c_void_p()
+    bf = np.array([40, 160, 40], np.int32)
+    pbf = bf.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    assert lib.afsk_group_plan_create(pbf, 3, None) == _native.E_INVALID_ARG
+    assert lib.afsk_group_plan_create(pbf, -1, ctypes.byref(h)) == _native.E_INVALID_ARG and not h
+    assert lib.afsk_group_plan_create(None, 3, ctypes.byref(h)) == _native.E_INVALID_ARG and not h
+    assert lib.afsk_group_plan_info(None, None, None, None, None, 0) == _native.E_INVALID_ARG
+    assert lib.afsk_group_plan_destroy(None) == 0
+    tail = (None, None, None, 14000, None, 0, None, None, None, None, None, None, None, 0, None)
+    assert lib.afsk_demod_batch_grouped(None, *tail) == _native.E_INVALID_ARG and "plan" in _native.last_error()
+    if _native.device_count() == 0:
+        assert lib.afsk_group_plan_create(pbf, 3, ctypes.byref(h)) == _native.E_NO_DEVICE and not h
+        with pytest.raises(_native.AfskNativeError):
+            batch.GroupPlan(bf)
+
+
+def test_host_bit_frames_length_is_checked_before_collapsing():
+    """an all-equal host sequence of the WRONG length must not be applied to every stream."""
+    assert batch._uniform_bit_frames(40, 7) == 40
+    assert batch._uniform_bit_frames([40], 7) == 40
+    assert batch._uniform_bit_frames([40] * 7, 7) == 40
+    assert batch._uniform_bit_frames([40, 160, 40], 3) is None
+    with pytest.raises(ValueError, match="1 or 7"):
+        batch._uniform_bit_frames([40, 40, 40], 7)
 
 
 def test_file_sizes_entry(tmp_path):

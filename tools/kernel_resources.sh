@@ -4,6 +4,8 @@
 cd "$(dirname "$0")/../afskmodem_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Rpass-analysis=kernel-resource-usage -c -o /dev/null"
 UNIFORM_BF=$(sed -n 's/^#define AFSK_\(FAST\|GP\)_BF_LIST(X)//p' afsk_demod_impl.h | tr -d 'X()' | tr '\n' ' ')
+WANT=$(sed -n 's/^static_assert(kUniformBfCount == \([0-9]*\),.*/\1/p' afsk_demod_impl.h)
+[ "$(echo $UNIFORM_BF | wc -w)" -eq "${WANT:-0}" ] || { echo "kernel_resources.sh: bit_frames lists do not match kUniformBfCount" >&2; exit 1; }
 {
   echo "afsk_demod_small.hip"; echo "afsk_demod_big.hip"
   for b in 0 $UNIFORM_BF; do echo "afsk_demod_uniform.hip -DAFSK_UNIFORM_BF=$b"; done
