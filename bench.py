@@ -905,6 +905,19 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
     return doc
 
 
+def cpu_calibration() -> dict | None:
+    """{file, pyref_over_reference (1200 baud), range} from the committed calibration of oracle/pyref.py against the
+    real reference (build container: tools/calibrate_cpu_reference.py); None when the file is absent."""
+    rel = os.path.join("profiles", "cpu_reference_calibration.json")
+    try:
+        cj = json.load(open(os.path.join(ROOT, rel)))
+        return {"file": rel, "pyref_over_reference": cj["pyref_over_reference_1200"],
+                "range": [cj["pyref_over_reference_min"], cj["pyref_over_reference_max"]],
+                "reference_msamples_per_s_1200_build_container": cj["by_baud"]["1200"]["reference_msamples_per_s"]}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s: float = 10.0, idx=None, label=""):
     """The CPU oracle (C port of the reference hot path) timed on this box's host cores on a bounded
     sample of the shard (the first ns streams, or the streams listed in idx), checked against the GPU's
@@ -957,11 +970,14 @@ def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s
                   f"{round(n1 * STREAM_LEN / dt1 / 1e6, 1)} Msamples/s",
         "single_thread_value": round(n1 * STREAM_LEN / dt1 / 1e6, 1),
         "python_reference_shaped_value": round(STREAM_LEN / dtp / 1e6, 3),
-        "python_reference_shaped_note": "oracle/pyref.py (pure-Python restatement, CPython, 1 core, "
-                                        f"{npy} streams); calibrated at 1.01-1.07x the real reference's "
-                                        "speed in the dev container (DESIGN.md 4.3); the real afskmodem.py "
-                                        "(1.3 Msamples/s/core at 1200 baud) was only ever timed in the build container",
+        "python_reference_shaped_note": f"oracle/pyref.py (pure-Python restatement, CPython, 1 core, {npy} streams); "
+                                        "its speed relative to the real afskmodem.py, measured in the build container on "
+                                        "the same streams, is in `calibration` (profiles/cpu_reference_calibration.json, "
+                                        "written by tools/calibrate_cpu_reference.py); the reference itself never travels",
     }
+    cal = cpu_calibration()
+    if cal:
+        doc["calibration"] = cal
     return doc, match / ns, ns
 
 

@@ -154,3 +154,24 @@ def test_full_record_goes_to_a_file_not_to_the_streams(tmp_path, monkeypatch, ca
     assert json.load(open(tmp_path / path)) == full
     cap = capsys.readouterr()
     assert cap.out == "" and cap.err == ""
+
+
+def test_cpu_baseline_calibration_is_a_tracked_artefact():
+    """bench.py's 'reference-shaped' CPU figure (oracle/pyref.py on one core) is read with a ratio measured against
+    the REAL reference in the build container: the ratio lives in a committed file written by
+    tools/calibrate_cpu_reference.py, and the bench line carries it."""
+    import bench
+    cj = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_calibration.json")))
+    assert cj["generated_by"] == "tools/calibrate_cpu_reference.py" and cj["cores_online"] >= 1 and cj["cpu"]
+    assert set(cj["by_baud"]) == {"300", "1200", "2400"}
+    for row in cj["by_baud"].values():
+        assert 0.8 <= row["pyref_over_reference"] <= 1.3, row
+        assert row["reference_msamples_per_s"] > 0 and row["c_oracle_over_reference"] > 10
+    assert 0.8 <= cj["pyref_over_reference_1200"] <= 1.3
+    cal = bench.cpu_calibration()
+    assert cal["file"] == "profiles/cpu_reference_calibration.json"
+    assert cal["pyref_over_reference"] == cj["pyref_over_reference_1200"]
+    # and it survives the compaction of the result line
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    full["cpu_baseline"]["calibration"] = cal
+    assert bench.compact_line(full, None)["cpu_baseline"]["calibration"] == cal
