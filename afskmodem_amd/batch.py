@@ -536,10 +536,24 @@ def read_wav_frames(filename: str) -> np.ndarray:
 
 
 def _c_names(filenames):
-    """(list of bytes, ctypes array of char*) for the file-ingest entries, built ONCE per batch (encoding
-    4096 names and filling the pointer array costs ~1.6 ms in CPython)."""
-    enc = [os.fsencode(f) for f in filenames]
-    return enc, (C.c_char_p * len(enc))(*enc)
+    """(keep-alive, ctypes char**) for the file-ingest entries, built ONCE per batch without a Python
+    object per name: the names joined into ONE NUL-separated blob (what ``os.fsencode`` would produce
+    for each), the pointer array computed with numpy from the positions of the NULs -- 0.5 ms for
+    4096 names instead of the 2.3 ms of ``(c_char_p * n)(*map(os.fsencode, names))``."""
+    import sys
+    strs = [f if type(f) is str else os.fsdecode(os.fspath(f)) for f in filenames]
+    if not strs:
+        return (b"", None), (C.c_char_p * 0)()
+    blob = ("\0".join(strs) + "\0").encode(sys.getfilesystemencoding(), sys.getfilesystemencodeerrors())
+    a = np.frombuffer(blob, np.uint8)
+    ends = np.flatnonzero(a == 0)
+    if ends.size != len(strs):
+        raise ValueError("embedded null byte")           # what open() says about such a name
+    ptrs = np.empty(len(strs), np.uint64)
+    ptrs[0] = 0
+    ptrs[1:] = ends[:-1] + 1
+    ptrs += np.uint64(a.ctypes.data)
+    return (blob, ptrs), C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p))
 
 
 def _wav_probe_c(arr, n):
@@ -558,8 +572,10 @@ def wav_probe(filenames):
     natively and in parallel.  Returns (data_offset int64 [n], data_bytes int64 [n], status int32
     [n]); status != 0 = not a plain PCM RIFF file (or unreadable).  No GPU needed."""
     names = list(filenames)
-    _, arr = _c_names(names)
-    return _wav_probe_c(arr, len(names))
+    keep, arr = _c_names(names)          # `arr` points into `keep`
+    res = _wav_probe_c(arr, len(names))
+    del keep
+    return res
 
 
 def load_wav_batch(filenames, device=None):
@@ -587,9 +603,10 @@ def load_wav_batch(filenames, device=None):
     p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
     sizes = np.zeros(n, np.int64)
     _native.check(lib.afsk_file_sizes(arr, n, p64(sizes)))
-    slot = ((np.maximum(sizes, 0) // 2) + 7) & ~np.int64(7)     # samples reserved per file, 16-byte granules
-    if int(slot.max()) > _native.MAX_STREAM_LEN:
-        raise ValueError("a stream longer than AFSK_MAX_STREAM_LEN samples")
+    # samples reserved per file, 16-byte granules.  st_size counts the header and any other chunk too, so a slot is
+    # only CLAMPED to the longest stream the kernels address: whether the data really fits is decided per file
+    # (AFSK_WAV_SLOT -> the stdlib fallback below), and the hard check is made on the real lengths after the ingest
+    slot = np.minimum(((np.maximum(sizes, 0) // 2) + 7) & ~np.int64(7), np.int64(_native.MAX_STREAM_LEN & ~7))
     offs = np.zeros(n, np.int64)
     offs[1:] = np.cumsum(slot[:-1])
     total = int(offs[-1] + slot[-1])

@@ -5,9 +5,11 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -62,7 +64,13 @@ struct ScratchCache {
     int device = -1;
     char* stage[2] = {nullptr, nullptr};            // pinned host windows (afsk_demod_streams_host)
     hipEvent_t stage_free[2] = {nullptr, nullptr};
+    // afsk_wav_ingest's staging ring: chunks 0 and 1 ARE stage[0] / stage[1]; 2 and 3 are allocated the first
+    // time a ring of more than 64 MiB is asked for; one event per ring slot
+    char* ring_extra[2] = {nullptr, nullptr};
+    hipEvent_t ring_sent[16] = {};
 };
+constexpr size_t kRingChunks = 4;
+constexpr int kMaxRingSlots = 16;
 ScratchCache g_scratch;
 
 class ScratchLease {
@@ -92,6 +100,8 @@ public:
                             (void)hipEventDestroy(g_scratch.stage_free[k]);
                             g_scratch.stage_free[k] = nullptr;
                         }
+                    for (hipEvent_t& ev : g_scratch.ring_sent)
+                        if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
                 }
                 const size_t want = (bytes + (bytes >> 3) + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
                 e = hipMalloc((void**)&g_scratch.ptr, want);
@@ -123,6 +133,32 @@ public:
         *e0 = g_scratch.stage_free[0]; *e1 = g_scratch.stage_free[1];
         return hipSuccess;
     }
+    // afsk_wav_ingest's ring of `slots` staging buffers of `window` bytes each (window divides 32 MiB,
+    // slots * window <= 128 MiB) and one event per slot; only with a blocking lease
+    hipError_t ring(size_t window, int slots, char** out_stage, hipEvent_t* out_sent) {
+        char* s0; char* s1; hipEvent_t e0, e1;
+        hipError_t e = staging(&s0, &s1, &e0, &e1);
+        if (e != hipSuccess) return e;
+        char* chunk[kRingChunks] = {s0, s1, nullptr, nullptr};
+        const size_t need = (size_t)slots * window;
+        for (size_t c = 2; c < kRingChunks && c * kStageBytes < need; c++) {
+            if (!g_scratch.ring_extra[c - 2]) {
+                e = hipHostMalloc((void**)&g_scratch.ring_extra[c - 2], kStageBytes, hipHostMallocPortable);
+                if (e != hipSuccess) { g_scratch.ring_extra[c - 2] = nullptr; return e; }
+            }
+        }
+        chunk[2] = g_scratch.ring_extra[0]; chunk[3] = g_scratch.ring_extra[1];
+        for (int k = 0; k < slots; k++) {
+            const size_t o = (size_t)k * window;
+            out_stage[k] = chunk[o / kStageBytes] + o % kStageBytes;
+            if (!g_scratch.ring_sent[k]) {
+                e = hipEventCreateWithFlags(&g_scratch.ring_sent[k], hipEventDisableTiming);
+                if (e != hipSuccess) { g_scratch.ring_sent[k] = nullptr; return e; }
+            }
+            out_sent[k] = g_scratch.ring_sent[k];
+        }
+        return hipSuccess;
+    }
 private:
     bool locked_ = false;
     char* private_ptr_ = nullptr;
@@ -152,6 +188,7 @@ struct ThreadStream {
     }
 };
 thread_local ThreadStream g_thread_stream;
+thread_local ThreadStream g_thread_stream2;      // afsk_wav_ingest alternates its H2D copies between the two
 
 struct CopyJob { char* dst; const char* src; size_t bytes; };
 
@@ -856,7 +893,10 @@ int afsk_host_scratch_release(void) {
     for (int k = 0; k < 2; k++) {
         if (g_scratch.stage[k]) { (void)hipHostFree(g_scratch.stage[k]); g_scratch.stage[k] = nullptr; }
         if (g_scratch.stage_free[k]) { (void)hipEventDestroy(g_scratch.stage_free[k]); g_scratch.stage_free[k] = nullptr; }
+        if (g_scratch.ring_extra[k]) { (void)hipHostFree(g_scratch.ring_extra[k]); g_scratch.ring_extra[k] = nullptr; }
     }
+    for (hipEvent_t& ev : g_scratch.ring_sent)
+        if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     return AFSK_OK;
 }
 
@@ -1141,38 +1181,38 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
         if (prev_end > capacity_samples) return fail(AFSK_E_INVALID_ARG, "slot outside the device buffer");
     }
     if (int rc0 = require_device()) return rc0;
-    // the two 32 MiB pinned windows as a ring of 2^k staging buffers (default 4 x 16 MiB; AFSK_INGEST_WINDOW_MB
-    // = 4 / 8 / 16 / 32 for experiments: 9.9 - 11.2 ms per 4096 x 96 KB files whatever the size, 16 ... 64 threads)
-    static const size_t kIngestWindow = [] {
+    // Staging ring: kSlots pinned buffers of kWindow bytes (default 8 x 16 MiB = the two 32 MiB windows of the
+    // gather entry plus two more chunks allocated on first use; AFSK_INGEST_WINDOW_MB = 4 / 8 / 16 / 32 and
+    // AFSK_INGEST_SLOTS = 2 ... 16 for experiments, at most 128 MiB in all).
+    static const size_t kWindow = [] {
         const char* e = std::getenv("AFSK_INGEST_WINDOW_MB");
         const int mb = e ? std::atoi(e) : 16;
         return (size_t)((mb == 4 || mb == 8 || mb == 16 || mb == 32) ? mb : 16) << 20;
     }();
-    constexpr int kMaxIngestSlots = 16;
-    const int kIngestSlots = (int)(2 * kStageBytes / kIngestWindow);
+    static const int kSlots = [] {
+        const char* e = std::getenv("AFSK_INGEST_SLOTS");
+        const int want = e ? std::atoi(e) : 8;
+        const int most = (int)std::min<size_t>((size_t)kMaxRingSlots, kRingChunks * kStageBytes / kWindow);
+        return std::max(2, std::min(want, most));
+    }();
+    static const bool kStats = std::getenv("AFSK_INGEST_STATS") != nullptr;
     constexpr size_t kGapFill = 256;
     int rc = AFSK_OK;
-    hipStream_t stream = nullptr;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
     {
-        hipError_t e = g_thread_stream.get(&stream);
-        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
+        hipError_t e = g_thread_stream.get(&copy_stream[0]);
+        if (e == hipSuccess) e = g_thread_stream2.get(&copy_stream[1]);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry streams)");
     }
     ScratchLease lease;
     char* d_unused = nullptr;
-    char* stage2[2];
-    hipEvent_t unused_ev[2];
+    char* stage[kMaxRingSlots];
+    hipEvent_t sent[kMaxRingSlots];
     {
-        hipError_t e = lease.acquire(1, &d_unused, /*block=*/true);    // owns the staging windows
+        hipError_t e = lease.acquire(1, &d_unused, /*block=*/true);    // owns the staging ring
         if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-entry scratch)");
-        e = lease.staging(&stage2[0], &stage2[1], &unused_ev[0], &unused_ev[1]);
-        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (staging)");
-    }
-    char* stage[kMaxIngestSlots];
-    hipEvent_t sent[kMaxIngestSlots];
-    for (int k = 0; k < kMaxIngestSlots; k++) {
-        sent[k] = nullptr;
-        const size_t o = (size_t)k * kIngestWindow;
-        stage[k] = o < kStageBytes ? stage2[0] + o : stage2[1] + (o - kStageBytes);
+        e = lease.ring(kWindow, kSlots, stage, sent);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc / hipEventCreate (staging ring)");
     }
 
     struct Piece { size_t file; size_t win; size_t slot_lo; size_t bytes; size_t stage_off; };
@@ -1194,16 +1234,16 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
             size_t done = 0;
             while (done < cap) {
                 const size_t p0 = b0 + done;
-                if (open_w && (p0 > w_b1 + kGapFill || p0 - w_b0 >= kIngestWindow)) close_window();
+                if (open_w && (p0 > w_b1 + kGapFill || p0 - w_b0 >= kWindow)) close_window();
                 if (!open_w) { w_b0 = w_b1 = p0; open_w = true; }
-                const size_t room = kIngestWindow - (p0 - w_b0);
+                const size_t room = kWindow - (p0 - w_b0);
                 const size_t take = std::min(cap - done, room);
                 // a whole slot that does not fit the rest of this window starts the next one
-                if (take < cap - done && done == 0 && cap <= kIngestWindow && p0 != w_b0) { close_window(); continue; }
+                if (take < cap - done && done == 0 && cap <= kWindow && p0 != w_b0) { close_window(); continue; }
                 pieces.push_back({s, wins.size(), done, take, p0 - w_b0});
                 done += take;
                 w_b1 = p0 + take;
-                if (w_b1 - w_b0 >= kIngestWindow) close_window();
+                if (w_b1 - w_b0 >= kWindow) close_window();
             }
         }
         close_window();
@@ -1212,50 +1252,123 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
     std::vector<std::atomic<int>> remaining(std::max<size_t>(nwin, 1));
     for (auto& r : remaining) r.store(0);
     for (const Piece& pc : pieces) if (pc.win < nwin) remaining[pc.win].fetch_add(1);
-    std::atomic<long> released{(long)std::min<size_t>((size_t)kIngestSlots, nwin)};
+    // Hand-over between the pool threads (fill) and the calling thread (send), under ONE mutex and two
+    // condition variables -- nobody spins: `released` = windows whose staging buffer may be filled (a filler
+    // whose piece lies beyond it sleeps on cv_released); a filler that completes a window wakes the sender
+    // (cv_filled).
+    std::mutex hand_mu;
+    std::condition_variable cv_released, cv_filled;
+    long released = (long)std::min<size_t>((size_t)kSlots, nwin);
     std::atomic<int> failed{0};
     std::atomic<long> io_failed_file{-1};
+    // stats (AFSK_INGEST_STATS): nanoseconds summed over the fillers / spent by the sender
+    std::atomic<long long> ns_wait_release{0}, ns_open{0}, ns_read{0}, ns_close{0}, n_fast{0};
+    long long ns_wait_fill = 0, ns_wait_sent = 0, ns_issue = 0;
+    auto now_ns = [] { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                           std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const long long t_begin = now_ns();
 
     auto fill_piece = [&](size_t i) {
         const Piece& pc = pieces[i];
-        while ((long)pc.win >= released.load(std::memory_order_acquire) && !failed.load(std::memory_order_relaxed))
-            std::this_thread::yield();
-        char* dst = pc.win < nwin ? stage[pc.win % kIngestSlots] + pc.stage_off : nullptr;
+        {
+            const long long t0 = kStats ? now_ns() : 0;
+            std::unique_lock<std::mutex> lk(hand_mu);
+            cv_released.wait(lk, [&] { return (long)pc.win < released || failed.load(std::memory_order_relaxed); });
+            if (kStats) ns_wait_release.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+        }
+        char* dst = pc.win < nwin ? stage[pc.win % (size_t)kSlots] + pc.stage_off : nullptr;
         if (!failed.load(std::memory_order_relaxed)) {
             int64_t doff = 0, dbytes = 0;
             int st = AFSK_WAV_IO;
+            long long t0 = kStats ? now_ns() : 0;
             const int fd = open(paths[pc.file], O_RDONLY | O_CLOEXEC);
-            if (fd >= 0) st = wav_probe_fd(fd, &doff, &dbytes);
+            if (kStats) { const long long t1 = now_ns(); ns_open.fetch_add(t1 - t0, std::memory_order_relaxed); t0 = t1; }
             const size_t cap = (size_t)slot_samples[pc.file] * 2;
-            size_t usable = st == AFSK_WAV_OK ? ((size_t)dbytes & ~(size_t)1) : 0;
-            if (usable > cap) { st = AFSK_WAV_SLOT; usable = 0; }          // the caller's slot is too small: left to the caller
-            if (pc.slot_lo == 0) { out_data_offset[pc.file] = doff; out_data_bytes[pc.file] = dbytes; out_status[pc.file] = st; }
-            const size_t lo = std::min(usable, pc.slot_lo), hi = std::min(usable, pc.slot_lo + pc.bytes);
-            if (hi > lo && !pread_all(fd, dst, hi - lo, doff + (int64_t)lo)) {
-                io_failed_file.store((long)pc.file);
-                failed.store(1);
+            bool have_data = false;
+            // The common file -- a canonical 44-byte header ('RIFF' size 'WAVE' 'fmt ' 16 ... 'data' size, what the
+            // stdlib writer behind SoundOutput.writeToFile produces, ref:256-263) whose whole data chunk is this
+            // one piece -- is read with ONE preadv: header into a local buffer, data straight into the staging
+            // slot.  Anything else (more chunks, odd sizes, a piece of a split slot) takes the general walk below.
+            if (fd >= 0 && pc.slot_lo == 0 && pc.bytes == cap && cap > 0) {
+                unsigned char hdr[44];
+                struct iovec iov[2] = {{hdr, sizeof hdr}, {dst, cap}};
+                const ssize_t got = preadv(fd, iov, 2, 0);
+                if (got >= 44 && std::memcmp(hdr, "RIFF", 4) == 0 && std::memcmp(hdr + 8, "WAVEfmt ", 8) == 0 &&
+                    le32(hdr + 16) == 16 && std::memcmp(hdr + 36, "data", 4) == 0) {
+                    const uint32_t tag = le16(hdr + 20), channels = le16(hdr + 22), width = (le16(hdr + 34) + 7) / 8;
+                    const int64_t framesize = (int64_t)channels * width;
+                    const int64_t csize = (int64_t)le32(hdr + 40);
+                    const int64_t fsize_min = 44 + (int64_t)(got - 44);          // bytes the file is known to hold
+                    // the file ended inside what we asked for (short read), or holds exactly header + slot: its size is known
+                    const bool size_known = (size_t)(got - 44) < cap || fsize_min == (int64_t)(44 + cap);
+                    if (tag == 1 && framesize > 0 && size_known) {
+                        struct stat sb;
+                        int64_t fsize = fsize_min;
+                        if ((size_t)(got - 44) == cap && fstat(fd, &sb) == 0) fsize = (int64_t)sb.st_size;
+                        const int64_t form_end = std::min<int64_t>(fsize, 8 + (int64_t)le32(hdr + 4));
+                        const int64_t want = (csize / framesize) * framesize;
+                        const int64_t avail = std::max<int64_t>(0, form_end - 44);
+                        doff = 44; dbytes = std::min(want, avail);
+                        const size_t usable = (size_t)dbytes & ~(size_t)1;
+                        if (usable <= cap && usable <= (size_t)(got - 44)) {
+                            st = AFSK_WAV_OK;
+                            have_data = true;
+                            out_data_offset[pc.file] = doff; out_data_bytes[pc.file] = dbytes; out_status[pc.file] = st;
+                            if (cap > usable) std::memset(dst + usable, 0, cap - usable);   // rest of the slot: zeros
+                            if (kStats) n_fast.fetch_add(1, std::memory_order_relaxed);
+                        }
+                    }
+                }
             }
-            if (dst && pc.bytes > hi - lo) std::memset(dst + (hi - lo), 0, pc.bytes - (hi - lo));   // rest of the slot: zeros
+            if (!have_data) {
+                if (fd >= 0) st = wav_probe_fd(fd, &doff, &dbytes);
+                size_t usable = st == AFSK_WAV_OK ? ((size_t)dbytes & ~(size_t)1) : 0;
+                if (usable > cap) { st = AFSK_WAV_SLOT; usable = 0; }          // the caller's slot is too small: left to the caller
+                if (pc.slot_lo == 0) { out_data_offset[pc.file] = doff; out_data_bytes[pc.file] = dbytes; out_status[pc.file] = st; }
+                const size_t lo = std::min(usable, pc.slot_lo), hi = std::min(usable, pc.slot_lo + pc.bytes);
+                size_t have = 0;
+                if (hi > lo) {
+                    // a file that shrank between the walk and the read is that FILE's problem, not the batch's:
+                    // zeroed slot, status AFSK_WAV_IO, the caller's fallback reader reports it
+                    char* q = dst;
+                    size_t left = hi - lo;
+                    int64_t off = doff + (int64_t)lo;
+                    while (left > 0) {
+                        const ssize_t r = pread(fd, q, left, (off_t)off);
+                        if (r <= 0) break;
+                        q += r; off += r; left -= (size_t)r; have += (size_t)r;
+                    }
+                    if (left > 0) { out_status[pc.file] = AFSK_WAV_IO; have = 0; }
+                }
+                if (dst && pc.bytes > have) std::memset(dst + have, 0, pc.bytes - have);   // rest of the slot: zeros
+            }
+            if (kStats) { const long long t1 = now_ns(); ns_read.fetch_add(t1 - t0, std::memory_order_relaxed); t0 = t1; }
             if (fd >= 0) close(fd);
+            if (kStats) ns_close.fetch_add(now_ns() - t0, std::memory_order_relaxed);
         }
-        if (pc.win < nwin) remaining[pc.win].fetch_sub(1, std::memory_order_release);
+        if (pc.win < nwin && remaining[pc.win].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(hand_mu);               // last piece of the window: wake the sender
+            cv_filled.notify_one();
+        }
     };
 
     hipError_t herr = hipSuccess;
     const char* hwhat = "";
     auto coordinator = [&](bool have_workers) {
-        for (int k = 0; k < kIngestSlots && herr == hipSuccess; k++) {
-            herr = hipEventCreateWithFlags(&sent[k], hipEventDisableTiming);
-            hwhat = "hipEventCreateWithFlags";
-        }
         size_t next_serial = 0;                       // without pool threads the caller fills the pieces itself
         size_t gap_scan = 0;
         for (size_t w = 0; w < nwin && herr == hipSuccess && !failed.load(); w++) {
             if (!have_workers)
                 while (next_serial < npieces && pieces[next_serial].win <= w) fill_piece(next_serial++);
-            while (remaining[w].load(std::memory_order_acquire) != 0 && !failed.load()) std::this_thread::yield();
+            {
+                const long long t0 = kStats ? now_ns() : 0;
+                std::unique_lock<std::mutex> lk(hand_mu);
+                cv_filled.wait(lk, [&] { return remaining[w].load(std::memory_order_acquire) == 0 || failed.load(); });
+                if (kStats) ns_wait_fill += now_ns() - t0;
+            }
             if (failed.load()) break;
-            char* st = stage[w % kIngestSlots];
+            const long long t1 = kStats ? now_ns() : 0;
+            char* st = stage[w % (size_t)kSlots];
             // gaps of up to kGapFill bytes between two slots of the window travel with it as zeros
             size_t cur = 0;
             for (; gap_scan < npieces && pieces[gap_scan].win <= w; gap_scan++) {   // pieces are in window order
@@ -1264,34 +1377,59 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
                 if (pc.stage_off > cur) std::memset(st + cur, 0, pc.stage_off - cur);
                 cur = std::max(cur, pc.stage_off + pc.bytes);
             }
+            // windows alternate between two copy streams (disjoint device ranges: no order needed between them),
+            // so the next transfer is already queued when one ends
+            hipStream_t cs = copy_stream[w & 1];
             if (wins[w].bytes > 0) {
-                herr = hipMemcpyAsync((char*)d_samples + wins[w].dev_b0, st, wins[w].bytes, hipMemcpyHostToDevice, stream);
+                herr = hipMemcpyAsync((char*)d_samples + wins[w].dev_b0, st, wins[w].bytes, hipMemcpyHostToDevice, cs);
                 hwhat = "H2D samples";
                 if (herr != hipSuccess) break;
             }
-            herr = hipEventRecord(sent[w % kIngestSlots], stream);
+            herr = hipEventRecord(sent[w % (size_t)kSlots], cs);
             hwhat = "hipEventRecord";
             if (herr != hipSuccess) break;
-            if (w >= 1) {                             // window w - 1 has left its staging buffer: window w - 1 + slots may fill it
-                herr = hipEventSynchronize(sent[(w - 1) % kIngestSlots]);
+            const long long t2 = kStats ? now_ns() : 0;
+            if (kStats) ns_issue += t2 - t1;
+            // keep two transfers queued: only when window w - 1 has left its staging buffer is that buffer handed
+            // to the fillers of window w - 1 + kSlots
+            if (w >= 1) {
+                herr = hipEventSynchronize(sent[(w - 1) % (size_t)kSlots]);
                 hwhat = "hipEventSynchronize";
-                released.store((long)(w + (size_t)kIngestSlots), std::memory_order_release);
+                if (kStats) ns_wait_sent += now_ns() - t2;
+                {
+                    std::lock_guard<std::mutex> lk(hand_mu);
+                    released = (long)(w + (size_t)kSlots);
+                }
+                cv_released.notify_all();
             }
         }
         if (herr != hipSuccess || failed.load()) failed.store(1);
-        released.store(std::numeric_limits<long>::max(), std::memory_order_release);   // nobody waits any more
+        {
+            std::lock_guard<std::mutex> lk(hand_mu);
+            released = std::numeric_limits<long>::max();           // nobody waits any more
+        }
+        cv_released.notify_all();
         if (!have_workers)
             while (next_serial < npieces) fill_piece(next_serial++);
     };
-    io_pool().run_split(npieces, io_threads(), fill_piece, coordinator);
+    // as many fillers as can work on released windows at once, within the pool's size
+    const unsigned width = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, npieces));
+    io_pool().run_split(npieces, width, fill_piece, coordinator);
     if (herr != hipSuccess) rc = hip_fail(herr, hwhat);
     else if (io_failed_file.load() >= 0) rc = fail(AFSK_E_HOST, std::string("cannot read ") + paths[io_failed_file.load()]);
-    {
-        hipError_t e = hipStreamSynchronize(stream);          // nothing may still read the staging buffers
+    for (int k = 0; k < 2; k++) {
+        hipError_t e = hipStreamSynchronize(copy_stream[k]);  // nothing may still read the staging buffers
         if (e != hipSuccess && rc == AFSK_OK) rc = hip_fail(e, "hipStreamSynchronize");
     }
-    for (int k = 0; k < kIngestSlots; k++)
-        if (sent[k]) (void)hipEventDestroy(sent[k]);
+    if (kStats) {
+        const double ms = 1e-6;
+        std::fprintf(stderr, "afsk_wav_ingest: %zu files, %zu windows of %zu MiB x %d slots, %u fillers, %.2f ms total | sender: "
+                     "wait-filled %.2f issue %.2f wait-sent %.2f ms | fillers (sum over threads): wait-release %.2f open %.2f "
+                     "read %.2f close %.2f ms, one-preadv files %lld\n", n, nwin, kWindow >> 20, kSlots, width,
+                     (now_ns() - t_begin) * ms, ns_wait_fill * ms, ns_issue * ms, ns_wait_sent * ms,
+                     ns_wait_release.load() * ms, ns_open.load() * ms, ns_read.load() * ms, ns_close.load() * ms,
+                     (long long)n_fast.load());
+    }
     return rc;
 }
 

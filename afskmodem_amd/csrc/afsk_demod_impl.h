@@ -265,6 +265,9 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     switch (bf) {
 #define AFSK_X(B) case B: demod_stream_fast<B, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
         AFSK_FAST_BF_LIST(AFSK_X)
+#ifdef AFSK_MIXED_ALL
+        AFSK_GP_BF_LIST(AFSK_X)
+#endif
 #undef AFSK_X
         default:            // every other valid bit_frames: the run-time geometry on the same ring
             demod_stream_rt<FLAGS, BIG>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,

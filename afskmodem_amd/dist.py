@@ -57,22 +57,27 @@ def gather_flat(res, n_total: int, group=None, out=None):
 def gather_flat_to_root(res, n_total: int, dst: int = 0, group=None, out=None):
     """Equal shards, records wanted on ONE rank: every rank sends ``res.flat`` to rank ``dst``
     (``torch.distributed.gather``: over RCCL one direct transfer per rank into dst's xGMI links -- never a
-    ring -- and 1/world of the all-gather's traffic).  Returns the list of per-rank DemodResult views on
+    ring -- and 1/world of the all-gather's traffic).  ``dst`` is a rank OF THE GROUP (0 ... world - 1, the
+    numbering ``shard_range`` uses; with the default group that is the global rank); it is translated to
+    the global rank ``torch.distributed.gather`` expects.  Returns the list of per-rank DemodResult views on
     ``dst`` and None on the other ranks.  ``out``: optional preallocated uint8 [world * flat] on dst."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)                       # group-local, like dst
+    if not 0 <= dst < world:
+        raise ValueError(f"dst {dst} is not a rank of a group of {world}")
+    dst_global = dst if group is None else dist.get_global_rank(group, dst)
     n_local, stride = int(res.bytes.shape[0]), int(res.bytes.shape[1])
     assert n_total == n_local * world, "gather_flat_to_root needs equal shards"
     flat = res.flat
     if rank != dst:
-        dist.gather(flat, None, dst=dst, group=group)
+        dist.gather(flat, None, dst=dst_global, group=group)
         return None
     if out is None:
         out = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
     per = flat.numel()
-    dist.gather(flat, [out[r * per: (r + 1) * per] for r in range(world)], dst=dst, group=group)
+    dist.gather(flat, [out[r * per: (r + 1) * per] for r in range(world)], dst=dst_global, group=group)
     return split_gathered(out, world, n_local, stride)
 
 

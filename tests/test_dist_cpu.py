@@ -72,6 +72,39 @@ def _worker_root(rank, world, port, n_total, stride, q):
     dist.destroy_process_group()
 
 
+def _worker_subgroup(rank, world, port, n_total, stride, q):
+    """a NON-default group whose local ranks differ from the global ones -- ranks {1, 2} of a world of 3.
+    ``dst`` is a rank of the group (like shard_range's): dst = 1 is global rank 2."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])                         # every rank of the world calls this
+    ok = True
+    if rank in (1, 2):
+        g_rank, g_world = dist.get_rank(grp), dist.get_world_size(grp)
+        b, e = adist.shard_range(n_total, g_rank, g_world)
+        parts = adist.gather_flat_to_root(_flat_result(b, e, stride), n_total, dst=1, group=grp)
+        if g_rank != 1:
+            ok = parts is None
+        else:
+            ok = rank == 2 and len(parts) == g_world
+            for r, part in enumerate(parts):
+                rb, re_ = adist.shard_range(n_total, r, g_world)
+                want = _fake_result(rb, re_, stride)
+                ok = ok and all(torch.equal(getattr(part, f), getattr(want, f))
+                                for f in ("bytes", "nbytes", "nbits", "clock_idx", "term_frame", "status"))
+        full = adist.gather_flat(_flat_result(b, e, stride), n_total, group=grp)
+        ok = ok and len(full) == g_world
+        try:
+            adist.gather_flat_to_root(_flat_result(b, e, stride), n_total, dst=2, group=grp)
+            ok = False
+        except ValueError:
+            pass
+    q.put((rank, ok, n_total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n_total, stride, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -131,3 +164,17 @@ def test_gather_world2_gloo(n_total, worker):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(ok and rows == n_total for _, ok, rows in res)
+
+
+def test_gather_to_root_in_a_subgroup_world3_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 3, port, 64, 40, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1, 2] and all(ok for _, ok, _ in res)

@@ -383,7 +383,7 @@ def synth_batch(torch, n, bauds, seed, total=48000, training_time=0.5, snr_db=No
     dev = "cuda:0"
     bauds = np.asarray([bauds[i % len(bauds)] for i in range(n)], np.int32)
     bf = (48000 // bauds).astype(np.int32)
-    plen = np.array([payload_len if payload_len is not None else synth.ONE_SECOND_PAYLOAD[int(b)]
+    plen = np.array([payload_len if payload_len is not None else synth.one_second_payload(int(b))
                      for b in bauds], np.int32)
     stride = int(plen.max()) if n else 1
     payload = synth.payload_bytes(seed, 0, n, max(stride, 1))
