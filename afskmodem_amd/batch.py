@@ -285,9 +285,10 @@ def _cached_plan(bit_frames, n: int, dev) -> "GroupPlan":
 
 class GroupPlan:
     """Rate-grouped dispatch plan of a mixed-baud batch whose ``bit_frames`` the host can see
-    (``afsk_group_plan_create``): the streams bucketed by rate, one uniform-kernel launch per rate on forked
-    side streams, outputs at the original stream numbers.  Build it once per batch layout and pass it to
-    ``demod_batch(..., plan=...)``; it belongs to the device that was current when it was built."""
+    (``afsk_group_plan_create``): the streams bucketed by rate, decoded by ONE launch that walks them bucket
+    by bucket (neighbouring wavefronts run the same rate's code), outputs at the original stream numbers.
+    Build it once per batch layout and pass it to ``demod_batch(..., plan=...)``; it belongs to the device
+    that was current when it was built."""
 
     def __init__(self, bit_frames, device=None):
         torch = _torch()
@@ -307,7 +308,7 @@ class GroupPlan:
         return self._h
 
     def groups(self) -> list[tuple[int, int]]:
-        """[(bit_frames, streams)] per launch, in launch order (bit_frames 0 = refused streams)."""
+        """[(bit_frames, streams)] per bucket, in launch order (largest first; bit_frames 0 = refused streams)."""
         ng, nn = C.c_int32(), C.c_int32()
         lib = _native.lib()
         _native.check(lib.afsk_group_plan_info(self.handle, C.byref(nn), C.byref(ng), None, None, 0))
@@ -347,7 +348,7 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
                    rows are defined up to ``DemodResult.symbols_demodulated``
     entry          "auto": ``afsk_demod_batch_uniform`` (a kernel compiled for exactly that
                    geometry) when the host can see that bit_frames is one value;
-                   ``afsk_demod_batch_grouped`` (one such kernel per rate, concurrently) when it can
+                   ``afsk_demod_batch_grouped`` (one launch over the rate-sorted streams) when it can
                    see several (a host sequence / array, or ``plan=``); the per-stream
                    ``afsk_demod_batch`` / ``_ex`` for a device tensor.  "uniform" / "grouped" / "mixed"
                    force one.  The uniform entry raises AFSK_E_INVALID_BAUD for an invalid value

@@ -460,34 +460,32 @@ int wav_probe_fd(int fd, int64_t* data_off, int64_t* data_bytes) {
 
 
 // ---- rate-grouped dispatch of a mixed-baud batch (afsk_demod_batch_grouped) -----------------------------
-// The host can see bit_frames: the streams are bucketed by value, every bucket is one launch of the uniform
-// kernel compiled for exactly that symbol geometry (wave w of the launch decodes stream index[first + w]),
-// and the launches run CONCURRENTLY on side streams forked from and joined back into the caller's stream
-// with events only (no host synchronisation: the pattern a stream capture records as a fork / join).
+// The host can see bit_frames: the streams are bucketed by value and the batch is decoded by ONE launch of the
+// per-stream kernel (every geometry a Receiver can have is compiled into it) that walks the streams BUCKET BY
+// BUCKET through an index list, so that the waves resident on a CU at any time run the same geometry's code
+// (wave w decodes stream index[w]; every per-stream array stays indexed by the stream number).
+// Measured alternatives (profiles/r4_exp2_grouped_modes.txt): one launch of the uniform kernel per bucket --
+// on side streams forked / joined with events, or one after the other -- loses 2 ... 70 % to the cross-queue
+// hand-over (~27 us per step) and to kernels of different queues hardly overlapping on gfx950
+// (hipExtAnyOrderLaunch is not honoured there); the rate-sorted single launch gains 3 ... 12 % over stream
+// order when four or more rates are mixed and loses 2 % with three (config #3), hence kSortFromGroups.
 struct GroupPlan {
     struct Group { int32_t bf; int32_t first; int32_t count; };
-    static constexpr int kMaxSide = 7;           // concurrent launches besides the caller's stream
+    static constexpr size_t kSortFromGroups = 4;  // fewer distinct rates: stream order (no index list)
     int device = -1;
     int32_t n = 0;
-    std::vector<Group> groups;                   // valid rates, largest bucket first; then bf <= 0: refused streams
-    std::vector<int32_t> h_index;                // the permutation, bucket after bucket
-    int32_t* d_index = nullptr;
+    std::vector<Group> groups;                   // valid rates, largest bucket first; then bf 0: the refused streams
+    std::vector<int32_t> h_upload;               // [n] index list (bucket after bucket) + [n] bit_frames by stream number
+    int32_t* d_index = nullptr;                  // [n] the permutation; followed, in the same storage, by
+    int32_t* d_bf = nullptr;                     // [n] bit_frames by stream number (the kernel's per-stream switch reads it)
     bool own_index = false;
-    hipStream_t side[kMaxSide] = {};
-    hipEvent_t fork = nullptr;
-    hipEvent_t join[kMaxSide] = {};
-    int n_side = 0;
 
     ~GroupPlan() {
-        for (int k = 0; k < kMaxSide; k++) {
-            if (join[k]) (void)hipEventDestroy(join[k]);
-            if (side[k]) (void)hipStreamDestroy(side[k]);
-        }
-        if (fork) (void)hipEventDestroy(fork);
         if (own_index && d_index) (void)hipFree(d_index);
     }
 
     static bool valid_bf(int32_t bf) { return bf >= 4 && (bf & 3) == 0 && 2 * bf < AFSK_SYNC_WINDOW; }
+    bool sorted() const { return groups.size() >= kSortFromGroups; }
 
     // host part: buckets and permutation (stable inside a bucket: ascending stream number)
     void bucket(const int32_t* h_bf, int32_t n_streams) {
@@ -507,70 +505,42 @@ struct GroupPlan {
             cursor[(size_t)bf] = first;
             first += count[(size_t)bf];
         }
-        h_index.resize((size_t)n);
-        for (int32_t s = 0; s < n; s++) h_index[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+        h_upload.resize(2 * (size_t)n);
+        for (int32_t s = 0; s < n; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+        if (n > 0) std::memcpy(h_upload.data() + n, h_bf, (size_t)n * 4);
     }
 
-    // device part: side streams + events on the current device; the index list either in storage the caller
-    // provides (copied asynchronously on `copy_stream`, which every launch of this plan must follow) or in an
-    // allocation of its own (copied synchronously)
+    // device part: index list + bit_frames either in storage the caller provides (2 n int32, copied
+    // asynchronously on `copy_stream`, which every launch of this plan must follow) or in an allocation of its
+    // own (copied synchronously)
     hipError_t materialise(int32_t* index_storage, hipStream_t copy_stream) {
         hipError_t e = hipGetDevice(&device);
-        if (e != hipSuccess) return e;
-        int launches = 0;
-        for (const Group& g : groups) launches += g.count > 0;
-        n_side = std::min<int>(kMaxSide, std::max(0, launches - 1));
-        if (n_side > 0) {
-            e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-            if (e != hipSuccess) { fork = nullptr; return e; }
-        }
-        for (int k = 0; k < n_side; k++) {
-            e = hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking);
-            if (e != hipSuccess) { side[k] = nullptr; return e; }
-            e = hipEventCreateWithFlags(&join[k], hipEventDisableTiming);
-            if (e != hipSuccess) { join[k] = nullptr; return e; }
-        }
-        if (n == 0) return hipSuccess;
+        if (e != hipSuccess || n == 0) return e;
         if (index_storage) {
             d_index = index_storage;
-            return hipMemcpyAsync(d_index, h_index.data(), (size_t)n * 4, hipMemcpyHostToDevice, copy_stream);
+            d_bf = d_index + n;
+            return hipMemcpyAsync(d_index, h_upload.data(), (size_t)n * 8, hipMemcpyHostToDevice, copy_stream);
         }
-        e = hipMalloc((void**)&d_index, (size_t)n * 4);
+        e = hipMalloc((void**)&d_index, (size_t)n * 8);
         if (e != hipSuccess) { d_index = nullptr; return e; }
+        d_bf = d_index + n;
         own_index = true;
-        return hipMemcpy(d_index, h_index.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        return hipMemcpy(d_index, h_upload.data(), (size_t)n * 8, hipMemcpyHostToDevice);
     }
 
-    // one launch per bucket: bucket 0 on the caller's stream, the others round-robin on the side streams
+    // ONE launch: the uniform kernel when the whole batch is one valid rate, else the per-stream kernel
+    // (in bucket order from kSortFromGroups rates on); a stream with an invalid bit_frames gets status 3 from
+    // the kernel itself.  Nothing but a kernel launch: asynchronous, capture-safe, no state shared between calls.
     hipError_t launch(afsk::DemodArgs a, hipStream_t stream) const {
-        hipError_t e = hipSuccess;
-        if (n_side > 0) {
-            e = hipEventRecord(fork, stream);
-            if (e != hipSuccess) return e;
-            for (int k = 0; k < n_side; k++) {
-                e = hipStreamWaitEvent(side[k], fork, 0);
-                if (e != hipSuccess) return e;
-            }
-        }
-        int li = 0;
-        for (const Group& g : groups) {
-            if (g.count <= 0) continue;
-            hipStream_t st = (li == 0 || n_side == 0) ? stream : side[(li - 1) % n_side];
-            li++;
-            a.stream_index = d_index + g.first;
-            a.n_streams = g.count;
+        a.n_streams = n;
+        if (groups.size() == 1 && groups[0].bf > 0) {
             a.bit_frames = nullptr;
-            a.uniform_bit_frames = g.bf;
-            e = g.bf > 0 ? afsk::launch_demod_uniform(a, st) : afsk::launch_refuse(a, AFSK_ST_INVALID_BAUD, st);
-            if (e != hipSuccess) break;
+            a.uniform_bit_frames = groups[0].bf;
+            return afsk::launch_demod_uniform(a, stream);
         }
-        // join even after a failed launch: the caller's stream must not run ahead of launches already queued
-        for (int k = 0; k < n_side; k++) {
-            hipError_t e2 = hipEventRecord(join[k], side[k]);
-            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(stream, join[k], 0);
-            if (e == hipSuccess) e = e2;
-        }
-        return e;
+        a.bit_frames = d_bf;
+        a.stream_index = sorted() ? d_index : nullptr;
+        return afsk::launch_demod(a, stream);
     }
 };
 
@@ -705,7 +675,7 @@ int afsk_group_plan_create(const int32_t* bit_frames_host, int32_t n_streams, af
         std::unique_ptr<afsk_group_plan> pl(new afsk_group_plan());
         pl->p.bucket(bit_frames_host, n_streams);
         hipError_t e = pl->p.materialise(nullptr, nullptr);
-        if (e != hipSuccess) return hip_fail(e, "afsk_group_plan_create (streams / events / index list)");
+        if (e != hipSuccess) return hip_fail(e, "afsk_group_plan_create (index list)");
         *out_plan = pl.release();
         return AFSK_OK;
     });
@@ -724,7 +694,7 @@ int afsk_group_plan_info(const afsk_group_plan* plan, int32_t* out_n_streams, in
 }
 
 int afsk_group_plan_destroy(afsk_group_plan* plan) {
-    delete plan;      // streams, events and the index list; the caller has synchronised its launches
+    delete plan;      // the index list; the caller has synchronised its launches
     return AFSK_OK;
 }
 
@@ -754,11 +724,11 @@ int afsk_demod_batch_grouped(const afsk_group_plan* plan, const int16_t* samples
     a.out_margins = margin_stride > 0 ? out_margins : nullptr;
     a.margin_stride = margin_stride;
     hipError_t e = plan->p.launch(a, (hipStream_t)hip_stream);
-    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel (grouped)");
+    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel (grouped)");
 }
 
 // The host entries see the bit_frames array: one value for all streams -> the uniform kernel;
-// several -> one uniform launch per rate (the index list lives in `index_storage`, n int32 of the
+// several -> the grouped dispatch (index list + bit_frames live in `index_storage`, 2 n int32 of the
 // caller's device scratch; `keep` owns the side streams until the caller has synchronised).
 static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples, const int64_t* stream_offset,
                              const int32_t* stream_len, const int32_t* d_bit_frames, int32_t amp_end_threshold,
@@ -777,7 +747,7 @@ static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples
     keep.reset(new GroupPlan());
     keep->bucket(h_bit_frames, n_streams);
     hipError_t e = keep->materialise(index_storage, stream);
-    if (e != hipSuccess) return hip_fail(e, "grouped dispatch (streams / events / index list)");
+    if (e != hipSuccess) return hip_fail(e, "grouped dispatch (index list)");
     afsk::DemodArgs a;
     a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
     a.amp_end = amp_end_threshold;
@@ -785,7 +755,7 @@ static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples
     a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
     a.out_status = out_status;
     e = keep->launch(a, stream);
-    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_uniform_kernel (grouped)");
+    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel (grouped)");
 }
 
 static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
@@ -818,7 +788,7 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
     // device layout: samples | meta = offsets, len, bf | out = 5 x int32 [n], bytes [n, stride]
     const size_t o_meta = (sample_bytes + 255) & ~(size_t)255;
     const size_t meta_bytes = n * 16;
-    const size_t o_out = o_meta + meta_bytes;
+    const size_t o_out = o_meta + meta_bytes + n * 8;      // + the index list and bit_frames of a grouped dispatch
     const size_t out_bytes_total = n * 20 + bytes_out;
     const size_t total = o_out + out_bytes_total;
     hipStream_t stream = nullptr;
@@ -827,7 +797,7 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
         if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
     }
     ScratchLease lease;
-    std::unique_ptr<GroupPlan> plan;      // mixed rates: side streams + events, alive until the final synchronise
+    std::unique_ptr<GroupPlan> plan;      // mixed rates: the host copy of the index list, alive until the final synchronise
     char* d_all = nullptr;
     // host staging: one H2D for the three index arrays, one D2H for all six outputs
     std::vector<char> h_meta(meta_bytes), h_out(out_bytes_total);
@@ -850,8 +820,7 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
                                i32 + 3 * n, i32 + 4 * n, stream,
-                               (int32_t*)(d_all + o_meta + n * 12),   // a grouped launch reads no bit_frames[]: its slot holds the index list
-                               plan);
+                               (int32_t*)(d_all + o_meta + n * 16), plan);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -932,7 +901,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
     const size_t sample_bytes = (size_t)(total_samples > 0 ? total_samples : 1) * 2;
     const size_t bytes_out = n * (size_t)out_stride;
     const size_t o_meta = (sample_bytes + 255) & ~(size_t)255;
-    const size_t o_out = o_meta + n * 16;
+    const size_t o_out = o_meta + n * 16 + n * 8;          // + the index list and bit_frames of a grouped dispatch
     const size_t out_bytes_total = n * 20 + bytes_out;
     hipStream_t stream = nullptr;
     {
@@ -940,7 +909,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
         if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
     }
     ScratchLease lease;
-    std::unique_ptr<GroupPlan> plan;      // mixed rates: side streams + events, alive until the final synchronise
+    std::unique_ptr<GroupPlan> plan;      // mixed rates: the host copy of the index list, alive until the final synchronise
     char* d_all = nullptr;
     char* stage[2];
     hipEvent_t stage_free[2];
@@ -987,8 +956,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
                                i32 + 3 * n, i32 + 4 * n, stream,
-                               (int32_t*)(d_all + o_meta + n * 12),   // a grouped launch reads no bit_frames[]: its slot holds the index list
-                               plan);
+                               (int32_t*)(d_all + o_meta + n * 16), plan);
         if (rc != AFSK_OK) goto done;
     }
     AFSK_HIP(hipMemcpyAsync(h_out.data(), d_all + o_out, out_bytes_total, hipMemcpyDeviceToHost, stream),
@@ -1224,6 +1192,9 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
         size_t w_b0 = 0, w_b1 = 0;                    // open window's device byte range
         bool open_w = false;
         auto close_window = [&] { if (open_w) { wins.push_back({w_b0, w_b1 - w_b0}); open_w = false; } };
+        // the first windows are SMALL (1, 2, 4 ... MiB up to the full window): the first transfer starts after a
+        // fraction of a millisecond of file reading instead of after a whole 16 MiB of it
+        auto win_cap = [&] { return std::min(kWindow, ((size_t)1 << 20) << std::min<size_t>(wins.size(), 6)); };
         for (size_t s = 0; s < n; s++) {
             const size_t b0 = (size_t)slot_offset[s] * 2, cap = (size_t)slot_samples[s] * 2;
             if (cap == 0) {                           // nothing to copy, but the file is still probed
@@ -1234,16 +1205,18 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
             size_t done = 0;
             while (done < cap) {
                 const size_t p0 = b0 + done;
-                if (open_w && (p0 > w_b1 + kGapFill || p0 - w_b0 >= kWindow)) close_window();
+                const size_t wcap = win_cap();
+                if (open_w && (p0 > w_b1 + kGapFill || p0 - w_b0 >= wcap)) close_window();
                 if (!open_w) { w_b0 = w_b1 = p0; open_w = true; }
-                const size_t room = kWindow - (p0 - w_b0);
+                const size_t wcap2 = win_cap();       // (closing a window may have moved on to a larger one)
+                const size_t room = wcap2 - (p0 - w_b0);
                 const size_t take = std::min(cap - done, room);
                 // a whole slot that does not fit the rest of this window starts the next one
-                if (take < cap - done && done == 0 && cap <= kWindow && p0 != w_b0) { close_window(); continue; }
+                if (take < cap - done && done == 0 && cap <= wcap2 && p0 != w_b0) { close_window(); continue; }
                 pieces.push_back({s, wins.size(), done, take, p0 - w_b0});
                 done += take;
                 w_b1 = p0 + take;
-                if (w_b1 - w_b0 >= kWindow) close_window();
+                if (w_b1 - w_b0 >= wcap2) close_window();
             }
         }
         close_window();

@@ -16,20 +16,6 @@ AFSK_GP_BF_LIST(AFSK_X)
 AFSK_X(0)
 #undef AFSK_X
 
-// grouped dispatch: the streams whose bit_frames the host found invalid get the refusal record the mixed
-// kernel would have written for them (status 3), without touching a sample
-__global__ __launch_bounds__(256) void refuse_kernel(DemodArgs a, int32_t status) {
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= a.n_streams) return;
-    store_refusal(a, a.stream_index ? a.stream_index[w] : w, 0, status);
-}
-
-hipError_t launch_refuse(const DemodArgs& a, int32_t status, hipStream_t stream) {
-    if (a.n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(refuse_kernel, dim3((a.n_streams + 255) / 256), dim3(256), 0, stream, a, status);
-    return hipGetLastError();
-}
-
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream) {
     if (a.n_streams <= 0) return hipSuccess;
     const int blocks = (a.n_streams + kWavesPerBlock - 1) / kWavesPerBlock;

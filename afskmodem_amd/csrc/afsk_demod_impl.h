@@ -194,10 +194,12 @@ constexpr int kFlagNoNt = 4;        // default cache policy instead of non-tempo
 // every bit_frames with a compile-time geometry (everything else: the run-time geometry)
 #define AFSK_FAST_BF_LIST(X) X(4) X(8) X(12) X(16) X(20) X(24) X(32) X(40) X(48) X(60) X(64) X(80) X(96) X(100) X(120) X(160) X(240) X(320) X(480)
 
-// bit_frames with a compile-time geometry in the UNIFORM kernels only (general pieces, afsk_demod_fast.h):
+// bit_frames whose compile-time geometry is built from the general pieces (afsk_demod_fast.h):
 // the other values a Receiver can be built for -- 48000 / baud a divisor of 48000 and a multiple of 4 --
-// i.e. 375, 250, 240, 160, 125, 120, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25 and 24 baud.  In a
-// mixed-baud launch they run the run-time geometry (the per-stream switch stays at AFSK_FAST_BF_LIST).
+// i.e. 375, 250, 240, 160, 125, 120, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25 and 24 baud.  Until r3 a
+// mixed-baud launch ran them on the run-time geometry (0.15 - 0.5 of the HBM peak); since r4 the per-stream
+// switch of demod_kernel_t covers both lists (0.61 - 0.73 on such mixes, +30 s of build time, 97 instead of 63
+// SGPR spills; config #3 unchanged at 0.81: profiles/EXPERIMENTS.md).
 #define AFSK_GP_BF_LIST(X) X(128) X(192) X(200) X(300) X(384) X(400) X(500) X(600) X(640) X(800) X(960) X(1000) X(1200) X(1500) X(1600) X(1920) X(2000)
 
 // how many uniform kernels the build must produce (build.sh scrapes the two lists above and checks its
@@ -265,9 +267,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     switch (bf) {
 #define AFSK_X(B) case B: demod_stream_fast<B, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
         AFSK_FAST_BF_LIST(AFSK_X)
-#ifdef AFSK_MIXED_ALL
-        AFSK_GP_BF_LIST(AFSK_X)
-#endif
+        AFSK_GP_BF_LIST(AFSK_X)      // r4: every rate a Receiver can be built for has its compile-time geometry here too
 #undef AFSK_X
         default:            // every other valid bit_frames: the run-time geometry on the same ring
             demod_stream_rt<FLAGS, BIG>(xs, len, bf, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym,
@@ -292,8 +292,11 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kLdsPerWave];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = blockIdx.x * WPB + wave;
-    if (s >= a.n_streams) return;
+    const int w = blockIdx.x * WPB + wave;
+    if (w >= a.n_streams) return;
+    // grouped dispatch, fused form: the launch walks a rate-sorted LIST of streams (neighbouring waves run the
+    // same geometry's code); bit_frames[] and every other per-stream array stay indexed by the stream number
+    const int s = a.stream_index ? __builtin_amdgcn_readfirstlane(a.stream_index[w]) : w;
     if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
         if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();
     }
@@ -347,10 +350,8 @@ __global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) 
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = blockIdx.x * WPB + wave;
-    if (w >= a.n_streams) return;
-    // grouped dispatch: the launch covers a LIST of streams (all of this kernel's rate); one scalar load
-    const int s = a.stream_index ? __builtin_amdgcn_readfirstlane(a.stream_index[w]) : w;
+    const int s = blockIdx.x * WPB + wave;
+    if (s >= a.n_streams) return;
     process_uniform_stream<BF, FLAGS, BIG>(a, s, lds_all + wave * kFastWaveLdsProduct, lane);
 }
 

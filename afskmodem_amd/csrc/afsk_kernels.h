@@ -25,8 +25,8 @@ struct DemodArgs {
     int32_t* out_margins = nullptr;               // [n, margin_stride] space_diff - mark_diff per symbol
     int32_t margin_stride = 0;
     int32_t uniform_bit_frames = 0;               // the one bit_frames of a uniform launch (afsk_demod_batch_uniform)
-    // grouped dispatch (afsk_demod_batch_grouped): wave w of a uniform launch decodes stream stream_index[w]
-    // (n_streams = entries of the list); every per-stream array, inputs and outputs, is addressed by that
+    // grouped dispatch (afsk_demod_batch_grouped): wave w of a per-stream launch decodes stream stream_index[w]
+    // (the rate-sorted list of all n_streams); every per-stream array, inputs and outputs, is addressed by that
     // stream number.  null = wave w decodes stream w.
     const int32_t* stream_index = nullptr;
 };
@@ -82,9 +82,6 @@ hipError_t launch_gate(const GateArgs& a, hipStream_t stream);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
 // one bit_frames (a.uniform_bit_frames, host-validated) for every stream of the launch
 hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream);
-// status `status` (and empty outputs) for the `count` streams listed in stream_index (grouped dispatch:
-// the streams whose host-side bit_frames is invalid)
-hipError_t launch_refuse(const DemodArgs& a, int32_t status, hipStream_t stream);
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);
 hipError_t launch_noise(NoiseArgs a, int32_t max_len, hipStream_t stream);
 

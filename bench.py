@@ -87,6 +87,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MALL_BYTES = 256 << 20  # Infinity Cache: inputs smaller than a few of these are rotated
 METRIC = "Msamples/s demodulated (batched 48 kHz streams) + decoded-byte match rate vs CPU ref"
 PAYLOAD_SEED = 2024
+RATE_ORDER = "cycle"            # --rate-order: how --bauds are laid over the streams of a custom workload
 
 
 def kernel_source_hash() -> str:
@@ -289,7 +290,7 @@ class Shard:
         for _ in range(copies - 1):
             self.inputs.append(x.clone())
         # one baud rate in the whole shard -> the Receiver-shaped uniform entry (bit_frames by value); several ->
-        # the rate-grouped dispatch (the host knows every stream's rate: one uniform kernel per rate, concurrently);
+        # the rate-grouped dispatch (the host knows every stream's rate: one launch over the rate-sorted streams);
         # --entry mixed forces the per-stream kernel (bit_frames[] in device memory) for A/B runs
         self.uniform_bf = int(self.bf_h[0]) if (len(set(bauds)) == 1 and ctx.args.entry != "mixed") else None
         self.plan = None
@@ -303,7 +304,10 @@ class Shard:
     def host_meta(first: int, n: int, bauds):
         from afskmodem_amd import synth
         gidx = np.arange(first, first + n)
-        baud_arr = np.asarray([bauds[i % len(bauds)] for i in gidx], np.int32)
+        if RATE_ORDER == "blocks":      # (A/B) rates in contiguous blocks of streams instead of cycling per stream
+            baud_arr = np.asarray([bauds[min(int(i - first) * len(bauds) // max(n, 1), len(bauds) - 1)] for i in gidx], np.int32)
+        else:
+            baud_arr = np.asarray([bauds[i % len(bauds)] for i in gidx], np.int32)
         bf_h = (48000 // baud_arr).astype(np.int32)
         plen_h = np.asarray([synth.one_second_payload(int(b)) for b in baud_arr], np.int32)
         pstride = max(synth.one_second_payload(int(b)) for b in bauds)
@@ -531,7 +535,7 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
         "streams_per_gpu": n_local,
         "entry": ("afsk_demod_batch_uniform" if sh.uniform_bf is not None else
                   "afsk_demod_batch_grouped" if sh.plan is not None else "afsk_demod_batch"),
-        "launches_per_step": 1 if sh.plan is None else len(sh.plan.groups()),
+        "rates_in_batch": 1 if sh.plan is None else len(sh.plan.groups()),
         "steps": steps, "warmup": warmup, "preroll_launches": preroll_launches,
         "value": round(samples_per_step * steps / elapsed / 1e6, 1),            # wall clock of the median region, fences included
         "value_event_time": round(samples_per_step * steps * n_regions / (event_ms * 1e-3) / 1e6, 1),   # HIP events, all regions
@@ -1213,6 +1217,8 @@ def main() -> None:
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--bauds", default="", help="with --workload custom: comma list of baud rates cycled over the streams")
+    ap.add_argument("--rate-order", default="cycle", choices=["cycle", "blocks"],
+                    help="custom workloads: baud of stream i = bauds[i %% k] (cycle) or contiguous blocks of n / k streams (blocks)")
     ap.add_argument("--preroll-ms", type=float, default=300.0,
                     help="untimed launches of the same kernel before the warm-up steps, so the "
                          "GPU clocks have settled (the first ~20 ms under load run 4-6 %% slower)")
@@ -1231,6 +1237,8 @@ def main() -> None:
                     help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
     args = ap.parse_args()
 
+    global RATE_ORDER
+    RATE_ORDER = args.rate_order
     if args.bauds:
         bl = tuple(int(b) for b in args.bauds.split(","))
         WORKLOADS["custom"] = (WORKLOADS["custom"][0], bl, None, f"custom: streams x 1 s, clean, bauds {list(bl)}, per GPU")

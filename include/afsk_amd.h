@@ -138,23 +138,25 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
 /*
  * Rate-grouped dispatch of a MIXED-baud batch whose bit_frames the HOST can see (a list of Receivers of
  * different baud rates, each with its own streams: one baud rate per Receiver, :275-284; streams are
- * independent, :354-381).  The plan buckets the streams by bit_frames once; afsk_demod_batch_grouped then
- * launches, per rate, the kernel of afsk_demod_batch_uniform compiled for exactly that symbol geometry over
- * the rate's list of streams, the launches running concurrently on the plan's side streams, forked from
- * and joined back into hip_stream with events only: no host synchronisation, asynchronous like every
- * device entry, and a stream capture of hip_stream records it as a fork / join.  Outputs land at the
- * ORIGINAL stream numbers, bit for bit what afsk_demod_batch_ex writes for the same bit_frames[] (a stream
- * with an invalid bit_frames gets status AFSK_ST_INVALID_BAUD).  afsk_demod_batch (bit_frames[] in device
- * memory, one launch, every geometry behind a per-stream switch) stays the entry for rates only the device
- * knows.
+ * independent, :354-381).  The plan buckets the streams by bit_frames once (a stable sort on the host, one
+ * upload of an index list + the bit_frames, 8 bytes per stream); afsk_demod_batch_grouped then decodes the
+ * batch with ONE kernel launch that walks the streams bucket by bucket, so that the wavefronts resident on a
+ * compute unit run the same rate's code: 3 - 12 % faster than stream order when four or more rates are mixed
+ * (below that the plan keeps stream order; one rate: the kernel of afsk_demod_batch_uniform).  Nothing but a
+ * kernel launch: asynchronous on hip_stream like every device entry, safe inside a stream capture, and
+ * calls may share a plan freely.  Outputs land at the ORIGINAL stream numbers, bit for bit what
+ * afsk_demod_batch_ex writes for the same bit_frames[] (a stream with an invalid bit_frames gets status
+ * AFSK_ST_INVALID_BAUD).  afsk_demod_batch (bit_frames[] in device memory, streams in the caller's order)
+ * stays the entry for rates only the device knows.
+ * (One launch of the uniform kernel per rate on forked HIP streams was measured and rejected: DESIGN.md 4.4.)
  *
- *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates the device index list (n int32) on
- *                           the current device, copies it (synchronous), creates up to 7 side streams.
- *  afsk_group_plan_info     n_streams, number of launches, and per launch (first `cap` of them) its
- *                           bit_frames (0 = the refused streams) and stream count; any pointer may be NULL
+ *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates 8 n bytes on the current device and
+ *                           fills them (synchronous).
+ *  afsk_group_plan_info     n_streams, number of buckets, and per bucket (first `cap` of them, in launch
+ *                           order: largest first) its bit_frames (0 = the refused streams) and stream count;
+ *                           any pointer may be NULL
  *  afsk_demod_batch_grouped every array as afsk_demod_batch_ex, indexed by the original stream number;
- *                           n_streams is the plan's.  Calls sharing one plan must be issued from one thread
- *                           at a time (they share the plan's events); they may be queued back to back.
+ *                           n_streams is the plan's
  *  afsk_group_plan_destroy  after the launches that use the plan have completed (NULL is fine)
  */
 typedef struct afsk_group_plan afsk_group_plan;
@@ -177,7 +179,7 @@ int afsk_demod_batch_grouped(const afsk_group_plan *plan, const int16_t *samples
  * NULL stream): they do not synchronise with the caller's own streams or with calls made by
  * other threads, and may be called concurrently (the reference's Receivers are independent
  * objects, afskmodem.py:275-284).  The host can see bit_frames[] here: one value -> the uniform kernel of
- * afsk_demod_batch_uniform, several -> the rate-grouped dispatch of afsk_demod_batch_grouped.  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
+ * afsk_demod_batch_uniform, several -> the rate-sorted launch of afsk_demod_batch_grouped.  stream_len[s] above AFSK_MAX_STREAM_LEN is rejected here (AFSK_E_INVALID_ARG).
  */
 int afsk_demod_batch_host(const int16_t *samples, int64_t total_samples,
                           const int64_t *stream_offset, const int32_t *stream_len,

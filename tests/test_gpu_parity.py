@@ -35,9 +35,9 @@ def entry(request, monkeypatch):
     """Every test of this file runs three times: with every device launch forced through the
     per-stream entry (afsk_demod_batch / _ex: the mixed-baud kernel), through the
     Receiver-shaped afsk_demod_batch_uniform (one kernel per bit_frames), and through the rate-grouped
-    dispatch afsk_demod_batch_grouped (the same uniform kernels over per-rate stream lists, concurrently,
-    outputs at the original stream numbers -- also for one-rate batches, so the index list is exercised
-    by every case).  A batch with several baud rates is, in the second run, split BY THE TEST into one
+    dispatch afsk_demod_batch_grouped (a plan built from the host-side rates: ONE launch of the per-stream
+    kernel that walks the streams bucket by bucket through an index list once four or more rates are mixed,
+    in stream order below that, the uniform kernel for one rate; outputs at the original stream numbers).  A batch with several baud rates is, in the second run, split BY THE TEST into one
     uniform launch per rate and scattered back into one result -- so every parity case below pins both
     kernel families and both ways of reaching the second.  (Host entries pick the uniform kernel or the
     grouped dispatch themselves, from their bit_frames array.)"""
@@ -884,10 +884,9 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
     stride = 64
     threads = os.cpu_count() or 16
     if entry == "grouped":
-        # two rates (a compile-time fast geometry and a general-piece one), n streams EACH, interleaved: both
-        # launches of the grouped dispatch are large ones (hint, and at 8256 warming) reading their streams
-        # through the index list, concurrently on two HIP streams
-        flat, off, ln, bf = large_launch_streams(2 * n, (1200, 375), 4242)
+        # five rates (fast and general-piece geometries), interleaved, in one rate-sorted launch of 2 n streams
+        # (hint and warming armed), every wave reaching its stream through the index list
+        flat, off, ln, bf = large_launch_streams(2 * n, (1200, 375, 300, 96, 6000), 4242)
         got = device_demod(torch, flat, off, ln, bf, stride=stride)
         want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=stride, n_threads=threads)
         assert_same(got, want, "grouped large launch")
@@ -1196,8 +1195,7 @@ def test_launch_is_graph_capture_safe(torch_cuda, entry):
     launches can be captured into a HIP graph and replayed (guideline: no hipMalloc / sync in
     the launch function).  Mixed entry: a three-rate batch with bit_frames on the device; uniform
     entry: one rate, bit_frames by value; grouped entry: the three-rate batch with a plan built BEFORE the
-    capture (the first, uncaptured call builds and caches it) -- the capture records the fork onto the plan's
-    side streams, three concurrent launches and the join."""
+    capture (the first, uncaptured call builds and caches it; a plan launch is nothing but a kernel launch)."""
     torch = torch_cuda
     b = synth_batch(torch, 256, (2400,) if entry == "uniform" else (300, 1200, 2400), seed=99)
     if entry == "uniform":
