@@ -1007,8 +1007,12 @@ def _sub_summary(name: str, rec: dict) -> dict:
     if "roofline" not in rec and all(isinstance(v, dict) for v in rec.values()):
         return {k: _sub_summary(k, v) for k, v in rec.items()}          # f2_gate: one entry per capture count
     if "by_baud" in rec:                                                 # rates_4096 / rates_65536
-        return _pick(rec, ("min_frac", "max_frac", "median_frac", "rates_below_0.60", "rates_below_0.75",
-                           "slowest", "all_round_trips_exact", "min_match_rate"))
+        out = _pick(rec, ("min_frac", "max_frac", "median_frac", "rates_below_0.60", "rates_below_0.75",
+                          "slowest", "all_round_trips_exact", "min_match_rate"))
+        for k in ("rates_below_0.60", "rates_below_0.75"):               # a long list becomes its length
+            if isinstance(out.get(k), list) and len(out[k]) > 6:
+                out[k] = len(out[k])
+        return out
     out = {"value": rec.get("value"), "frac": (rec.get("roofline") or {}).get("frac")}
     for k in ("match_rate", "oracle_match_rate", "decoded_match_rate"):
         if k in rec:
