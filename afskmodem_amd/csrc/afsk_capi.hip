@@ -4,6 +4,7 @@
 
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
@@ -366,11 +367,35 @@ void parallel_for(size_t n, unsigned max_threads, F&& body) {
     io_pool().run(n, max_threads, body);
 }
 
+// CPUs this process may really use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) where one
+// is set -- hardware_concurrency() reports every core of the host (256 on the GPU boxes, whose containers get
+// the time of 16), and a pool sized for cores the scheduler will not grant is throttled for whole 100 ms
+// periods (the 60 - 180 ms outliers of the r3 ingest) -- else the affinity mask / core count.
+unsigned usable_cpus() {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = 100000;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+        std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+        std::fclose(g);
+        if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(h, "%lld", &period) != 1) period = 100000;
+            std::fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return hw;
+}
+
 unsigned io_threads() {
     static const unsigned v = [] {
         const char* e = std::getenv("AFSK_IO_THREADS");
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(32u, hw);
+        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(32u, usable_cpus());
     }();
     return v;
 }

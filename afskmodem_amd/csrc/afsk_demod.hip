@@ -28,7 +28,7 @@ hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream) {
     if (a.n_streams <= 0) return hipSuccess;
     if (!bit_frames_valid(a.uniform_bit_frames)) return hipErrorInvalidValue;   // the C-ABI entry checks first
     const int blocks = (a.n_streams + kWavesPerBlock - 1) / kWavesPerBlock;
-    const bool big = a.n_streams >= kHintMinStreamsUniform;
+    const bool big = a.n_streams >= uniform_big_from(a.uniform_bit_frames);
     switch (a.uniform_bit_frames) {
 #define AFSK_X(B) case B: return launch_demod_uniform_##B(a, blocks, big, stream);
         AFSK_FAST_BF_LIST(AFSK_X)

@@ -73,6 +73,7 @@ constexpr int kWarmMinStreams = 8192;
 // with no loud probe at all still decodes, one demand fetch later.
 constexpr int kProbes = 64;               // one per lane; probes beyond the stream end cost nothing (range-checked)
 constexpr int kHintMinStreams = 6144;     // mixed-baud kernel: -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
+constexpr int kHintMinStreamsShort = 8192;     // uniform kernels of bit_frames 4 / 8 (large-launch form, hint and warming alike)
 constexpr int kHintMinStreamsUniform = 4096;   // uniform kernels (no scalar-register pressure): -0.8 ... -1.6 % at 4096 streams and 1.02 x
                                                // instead of 1.11 x the algorithmic bytes fetched; neutral at 2048
 
@@ -1092,8 +1093,10 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 //              120: two lanes per symbol, 120-byte pieces (8-byte aligned), quarter sums
 template <int BF>
 struct WmGeom {
-    static constexpr bool valid = BF == 60 || BF == 96 || BF == 100 || BF == 120 || BF == 240 || BF == 320 || BF == 480;
-    // lanes per symbol: a whole symbol (60), half a symbol (96 / 100 / 120), and for the long symbols of
+    static constexpr bool valid = BF == 60 || BF == 96 || BF == 100 || BF == 120 || BF == 128 || BF == 240 || BF == 320 || BF == 480;
+    // lanes per symbol: a whole symbol (60), half a symbol (96 / 100 / 120, and since r4 128 = 375 baud: 8 KiB
+    // rounds of eight 16-byte reads per lane, 0.746 -> 0.792 of peak at 65536 streams against its general-piece
+    // form with 4 KiB rounds), and for the long symbols of
     // 200 / 150 / 100 baud a piece that lies inside ONE quarter of the symbol (both templates constant
     // over it): 240 -> 4 x 60 samples, 320 -> 8 x 40, 480 -> 8 x 60
     static constexpr int LPS = BF >= 320 ? 8 : (BF >= 240 ? 4 : (BF >= 96 ? 2 : 1));
@@ -1395,23 +1398,18 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
 
-        uint32_t h = 0, amp = 0;
+        uint32_t h = 0;
 #pragma unroll
-        for (int d = 0; d < NB; d++) {
+        for (int d = 0; d < NB; d++)
             h = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, h);         // ref:344, 346-347
-            amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);                      // ref:94-98
-        }
         const uint32_t la = limit_pair_biased(x[NB]), lb = limit_pair_biased(x[NB + 1]);
         uint32_t mark = mark_hi ? h : FULL * (2u * NB) - h;
         uint32_t space = space_hi ? h : FULL * (2u * NB) - h;
         mark = __builtin_amdgcn_sad_u16(la, tmA, mark);
         space = __builtin_amdgcn_sad_u16(la, tsA, space);
-        amp = __builtin_amdgcn_sad_u16(x[NB] ^ kBias, kBias, amp);
         const uint32_t mb = __builtin_amdgcn_sad_u16(lb, lm, 0u), sb = __builtin_amdgcn_sad_u16(lb, ls, 0u);
-        const uint32_t ab = __builtin_amdgcn_sad_u16(x[NB + 1] ^ kBias, kBias, 0u);
         mark += two ? mb : 0u;
         space += two ? sb : 0u;
-        amp += two ? ab : 0u;
         mark = group_sum_last<LPS>(mark);
         space = group_sum_last<LPS>(space);
         const int k0 = r * SPP;
@@ -1420,7 +1418,15 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
         if (margins && part == LPS - 1 && k0 + sym < mlim) margins[k0 + sym] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < SPP ? (K - k0) : SPP;
         const uint64_t bmask = compress_bits_last<LPS>(__ballot(bit));
+        // the squelch amplitude (ref:94-98, ref:375) is only formed in passes that hold data symbols -- the
+        // reference does not evaluate it during training either (ref:361-366); r4: a quarter of the per-dword
+        // VALU work of the training rounds
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
+            uint32_t amp = 0;
+#pragma unroll
+            for (int d = 0; d <= NB; d++) amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
+            const uint32_t ab = __builtin_amdgcn_sad_u16(x[NB + 1] ^ kBias, kBias, 0u);
+            amp += two ? ab : 0u;
             const uint32_t asum = group_sum_last<LPS>(amp);
             return compress_bits_last<LPS>(__ballot(asum >= amp_thr));
         });
@@ -1729,7 +1735,7 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
 }
 
-template <int BF, int FLAGS, bool BIG = true>
+template <int BF, int FLAGS, bool BIG = true, bool UNIFORM = false>
 __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len, int32_t amp_end,
                                                   uint8_t* lds, int lane, RxState& st,
                                                   uint8_t* out_row, int out_stride, int& ci_out,
@@ -1787,10 +1793,12 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
     const int byte0 = 2 * ci;                                  // ring byte of symbol 0
     // Tail hint (see kProbes): for large launches, and only on the aligned round loops (a second copy of
-    // each, so that streams without the hint run exactly the code they ran before); not for bit_frames
-    // 4 / 8, whose five- and ten-slice rounds are so short of scalar registers that the two extra live
-    // values cost more than the saved traffic (+4 % at 6000 baud).
-    constexpr bool HINT = !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
+    // each, so that streams without the hint run exactly the code they ran before).  bit_frames 4 / 8 (five-
+    // and ten-slice rounds, short of scalar registers) take it only in their UNIFORM kernels and only from
+    // kHintMinStreamsShort streams on (r4: 12000 baud 0.709 -> 0.750 of peak at 65536 streams, 6000 baud
+    // 0.731 -> 0.750; at 4096 streams it costs them 3 %, and in the per-stream kernel, which carries every
+    // geometry's scalars, 1 - 2 %).
+    constexpr bool HINT = UNIFORM || !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);
     constexpr int kAlignMask = GP ? 0 : (WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15)));   // GP reads 2-byte-aligned dwords
     const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
     const bool hinted = HINT && hint && aligned;

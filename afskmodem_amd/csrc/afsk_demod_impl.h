@@ -307,6 +307,12 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     }
 }
 
+// launches of this many streams or more run the large-launch form of a uniform kernel (tail hint; L2 warming
+// from kWarmMinStreams); bit_frames 4 / 8 later than the others (kHintMinStreamsShort)
+__host__ __device__ constexpr int uniform_big_from(int bf) {
+    return (bf == 4 || bf == 8) ? kHintMinStreamsShort : kHintMinStreamsUniform;
+}
+
 // ---- one bit_frames for the whole launch (afsk_demod_batch_uniform) ------------------------------
 // BF > 0: the compile-time geometry of that value; BF == 0: the run-time geometry with
 // a.uniform_bit_frames (host-validated: valid and without a compile-time geometry).
@@ -321,7 +327,7 @@ __device__ __forceinline__ void process_uniform_stream(const DemodArgs& a, int s
     uint8_t* out_row = a.out_bytes + (int64_t)s * a.out_stride;
     int32_t* margins = a.out_margins ? a.out_margins + (int64_t)s * a.margin_stride : nullptr;
     const bool warm = a.n_streams >= kWarmMinStreams;
-    const bool hint = a.n_streams >= kHintMinStreamsUniform;
+    const bool hint = a.n_streams >= uniform_big_from(BF);
     RxState st;
     int32_t n_sym = 0;
     int ci = 0;
@@ -330,8 +336,8 @@ __device__ __forceinline__ void process_uniform_stream(const DemodArgs& a, int s
         if (lane == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
     }
     if constexpr (BF > 0) {
-        demod_stream_fast<BF, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps,
-                                          margins, a.margin_stride, warm, hint);
+        demod_stream_fast<BF, FLAGS, BIG, true>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps,
+                                                margins, a.margin_stride, warm, hint);
         store_result(a, s, lane, st, ci, n_sym, BF);
     } else {
         const int bf = a.uniform_bit_frames;
