@@ -450,6 +450,26 @@ def main():
     add_recipe("r3b/two_bursts_short_gap/1200", [["burst", p34, 1200, 0.5, w_len - 4800], ["zeros", 39],
                                                 ["burst", p34, 1200, 0.5, None]], 1200)
     add_recipe("r3b/two_bursts_odd_gap/2400", [["burst", p34, 2400, 0.5, None], ["zeros", 7], ["burst", p34, 2400, 0.5, None]], 2400)
+    # r4: 12000 and 6000 baud (one and two samples per quarter symbol) on IDEAL frames -- the wav writer's quirk
+    # (ref:239-244) destroys the 12000-baud mark tone, so until r4 that rate had a single reference case
+    rng8 = np.random.default_rng(20261101)
+    for baud in (12000, 6000):
+        pl = rng8.integers(0, 256, 40, dtype=np.uint8).tobytes().hex()
+        n_fr = len(GI.build_capture([["frames", pl, baud, 0.5, None]]))
+        add_recipe(f"r4/ideal/{baud}", [["frames", pl, baud, 0.5, None]], baud)
+        add_recipe(f"r4/ideal_tt0.05/{baud}", [["frames", pl, baud, 0.05, None], ["zeros", 3000]], baud)
+        for lead in (1, 2, 3, 5, 7, 4056, 5001):
+            add_recipe(f"r4/lead{lead}/{baud}", [["zeros", lead], ["frames", pl, baud, 0.5, None]], baud)
+        for extra in (0, 1, 3):
+            add_recipe(f"r4/no_tail+{extra}/{baud}", [["frames", pl, baud, 0.5, n_fr - 4800], ["zeros", extra]], baud)
+        for k, snr in enumerate((12, 9, 6, 4)):
+            add_recipe(f"r4/snr{snr}/{baud}", [["zeros", 2 * k + 1], ["frames", pl, baud, 0.5, None]], baud,
+                       noise=[300 + k, baud, snr_to_scale_q24(snr)])
+        add_recipe(f"r4/noise_lead/{baud}", [["noise", 3000, 17, 1 << 21], ["frames", pl, baud, 0.5, None]], baud)
+        add_recipe(f"r4/two_bursts/{baud}", [["frames", pl, baud, 0.5, None], ["zeros", 11], ["frames", pl, baud, 0.5, None]], baud)
+        add_recipe(f"r4/amp20000/{baud}", [["frames", pl, baud, 0.5, None]], baud, amp_end=20000)
+        big = rng8.integers(0, 256, 1500, dtype=np.uint8).tobytes().hex()
+        add_recipe(f"r4/long/{baud}", [["frames", big, baud, 0.5, None]], baud)
     G["decode_cases"] = cases
 
     # ---- 5b. live gate (Receiver.__listen ref:299-319) replayed over finite captures

@@ -60,6 +60,8 @@ def build_capture(recipe) -> np.ndarray:
     """A long capture from a list of segments (used by the live-gate cases):
     ["zeros", n] | ["noise", n, seed, scale_q24] (oracle integer noise on silence) |
     ["burst", payload_hex, baud, training_time, keep] (wav samples, first `keep` if not None) |
+    ["frames", payload_hex, baud, training_time, keep] (the ideal Transmitter frames: 12000 baud, whose mark tone
+    the wav writer's decimate / duplicate quirk destroys) |
     ["square", n, amplitude] (+a, -a, +a, ...) |
     ["burst_level", payload_hex, baud, training_time, keep, level] (the burst with +level / -level
     instead of full scale; silence stays 0) |
@@ -74,6 +76,9 @@ def build_capture(recipe) -> np.ndarray:
             parts.append(O.add_noise(np.zeros(seg[1], np.int16), seg[2], 0, seg[3]))
         elif kind == "burst":
             w = _wav(seg[1], seg[2], seg[3])
+            parts.append(w if seg[4] is None else w[: seg[4]])
+        elif kind == "frames":                       # the IDEAL Transmitter frames (no wav-writer quirk)
+            w = O.get_frames(bytes.fromhex(seg[1]), seg[2], seg[3])
             parts.append(w if seg[4] is None else w[: seg[4]])
         elif kind == "square":
             parts.append(np.tile(np.array([seg[2], -seg[2]], np.int16), seg[1] // 2))
