@@ -73,7 +73,11 @@ constexpr int kWarmMinStreams = 8192;
 // with no loud probe at all still decodes, one demand fetch later.
 constexpr int kProbes = 64;               // one per lane; probes beyond the stream end cost nothing (range-checked)
 constexpr int kHintMinStreams = 6144;     // mixed-baud kernel: -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
-constexpr int kHintMinStreamsShort = 8192;     // uniform kernels of bit_frames 4 / 8 (large-launch form, hint and warming alike)
+// uniform kernels of bit_frames 4 / 8 (large-launch form, hint and warming alike): 12000 baud gains from 8192
+// streams on (0.65 -> 0.68; 16384: 0.65 -> 0.71; 32768: 0.72 -> 0.77), 6000 baud loses 2 % at 8192 / 12288 and gains
+// from 16384 on (0.69 -> 0.71; 32768: 0.69 -> 0.76) -- profiles/r4_exp4_hint_short.txt
+constexpr int kHintMinStreamsShort4 = 8192;
+constexpr int kHintMinStreamsShort8 = 16384;
 constexpr int kHintMinStreamsUniform = 4096;   // uniform kernels (no scalar-register pressure): -0.8 ... -1.6 % at 4096 streams and 1.02 x
                                                // instead of 1.11 x the algorithmic bytes fetched; neutral at 2048
 
@@ -1795,7 +1799,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     // Tail hint (see kProbes): for large launches, and only on the aligned round loops (a second copy of
     // each, so that streams without the hint run exactly the code they ran before).  bit_frames 4 / 8 (five-
     // and ten-slice rounds, short of scalar registers) take it only in their UNIFORM kernels and only from
-    // kHintMinStreamsShort streams on (r4: 12000 baud 0.709 -> 0.750 of peak at 65536 streams, 6000 baud
+    // kHintMinStreamsShort4 / 8 streams on (r4: 12000 baud 0.709 -> 0.750 of peak at 65536 streams, 6000 baud
     // 0.731 -> 0.750; at 4096 streams it costs them 3 %, and in the per-stream kernel, which carries every
     // geometry's scalars, 1 - 2 %).
     constexpr bool HINT = UNIFORM || !(MULTI && MultiGeom<MULTI ? BF : 4>::SPL >= 5);

@@ -308,9 +308,9 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
 }
 
 // launches of this many streams or more run the large-launch form of a uniform kernel (tail hint; L2 warming
-// from kWarmMinStreams); bit_frames 4 / 8 later than the others (kHintMinStreamsShort)
+// from kWarmMinStreams); bit_frames 4 / 8 later than the others (kHintMinStreamsShort4 / 8)
 __host__ __device__ constexpr int uniform_big_from(int bf) {
-    return (bf == 4 || bf == 8) ? kHintMinStreamsShort : kHintMinStreamsUniform;
+    return bf == 4 ? kHintMinStreamsShort4 : (bf == 8 ? kHintMinStreamsShort8 : kHintMinStreamsUniform);
 }
 
 // ---- one bit_frames for the whole launch (afsk_demod_batch_uniform) ------------------------------

@@ -90,6 +90,30 @@ PAYLOAD_SEED = 2024
 RATE_ORDER = "cycle"            # --rate-order: how --bauds are laid over the streams of a custom workload
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: the cgroup CPU quota where one is set (the GPU boxes show all 256 cores
+    of the host to a container that gets the time of 16), else the affinity mask / core count.  The CPU baseline
+    runs on -- and reports as `cores` -- this many threads: threads beyond the quota only get throttled."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def kernel_source_hash() -> str:
     """sha256 over the demod kernel's sources (afsk_demod*.h/.hip + afsk_kernels.h): ties a
     committed rocprof figure (profiles/traffic_latest.json) to the kernel it was measured on."""
@@ -863,7 +887,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                             "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
                                           "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
                                           "(page cache warm: the files were just written)" % reps},
-               "host_cores": os.cpu_count(), "files_on": d.split(os.sep)[1] if os.sep in d else d}
+               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "files_on": d.split(os.sep)[1] if os.sep in d else d}
         del pin, devbuf
         return rec
     finally:
@@ -876,7 +900,7 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
     fraction of the HBM peak in algorithmic bytes, round trip to the modulated payloads and the CPU oracle
     on a sample.  (Below ~100 baud a 1 s stream holds 0 - 2 payload bytes: training, terminator and tail.)"""
     rows = {}
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     for baud in ALL_RATES:
         sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
         rec, aux = measure(ctx, sh, steps, warmup, 50.0, 0, 0.0)      # 50 ms pre-roll: every rate starts from settled clocks
@@ -968,6 +992,7 @@ def cpu_baseline_for(sh: Shard, res, got_payloads, ns: int, cores: int, budget_s
     dtp = (time.perf_counter() - t3) / npy
     doc = {
         "value": round(ns * STREAM_LEN / dtc / 1e6, 1), "unit": "Msamples/s", "cores": cores,
+        "host_cores": os.cpu_count(),      # what the host shows; `cores` = usable_cpus() = the threads used (cgroup quota)
         "kind": "port",
         "sample": f"{ns} streams of the same batch{label}, CPU oracle (C port of afskmodem.py hot path), "
                   f"{cores} threads, {reps} reps; single thread on {n1} streams: "
@@ -1056,13 +1081,14 @@ def compact_line(full: dict, full_path: str | None = None) -> dict:
     return line
 
 
-def write_full_record(full: dict, world: int) -> str | None:
-    """The full record (tens of KB) goes to gpurun_out/bench_full_n<N>.json -- never to stdout or stderr,
-    whose tails are all the driver keeps."""
+def write_full_record(full: dict, world: int, tag: str = "") -> str | None:
+    """The full record (tens of KB) goes to gpurun_out/bench_full_n<N>.json (the default run; an explicit
+    --workload adds its name, so side runs do not overwrite the headline's record) -- never to stdout or
+    stderr, whose tails are all the driver keeps."""
     for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
         try:
             os.makedirs(d, exist_ok=True)
-            path = os.path.join(d, f"bench_full_n{world}.json")
+            path = os.path.join(d, f"bench_full_n{world}{'_' + tag if tag else ''}.json")
             with open(path, "w") as f:
                 json.dump(full, f, indent=1)
             return os.path.relpath(path, ROOT)
@@ -1075,7 +1101,7 @@ def run_rank(args) -> None:
     ctx = Ctx(args)
     torch, dist = ctx.torch, ctx.dist
     world, rank = ctx.world, ctx.rank
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     src_hash = kernel_source_hash()
 
     pl = plan(world, args.workload, args.sub, args.streams)
@@ -1194,7 +1220,7 @@ def run_rank(args) -> None:
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
-        path = write_full_record(out, world)
+        path = write_full_record(out, world, args.workload)
         print(json.dumps(compact_line(out, path)), flush=True)
 
 
