@@ -1061,6 +1061,8 @@ static int wav_upload_impl(const char* const* paths, const int64_t* data_offset,
     std::vector<int> fds(n, -1);
     std::atomic<int> io_failed{-1};
     struct Piece { size_t file; int64_t file_off; char* dst; size_t bytes; bool last; };
+    constexpr size_t kZeroPiece = ~(size_t)0;             // Piece::file of a zero-filled alignment gap
+    constexpr size_t kUploadGapFill = 256;
     {
         // windows over the device byte range the streams cover; a window holds whole or partial
         // streams, each read by one pread straight into pinned memory
@@ -1078,12 +1080,24 @@ static int wav_upload_impl(const char* const* paths, const int64_t* data_offset,
             for (size_t s = s_cur; s < n; s++) {
                 const size_t b0 = (size_t)stream_offset[s] * 2, b1 = b0 + ((size_t)data_bytes[s] & ~(size_t)1);
                 if (b0 >= w1) break;
-                if (b1 <= w0) { s_cur = s + 1; continue; }
-                const size_t lo = std::max(b0, w0), hi = std::min(b1, w1);
-                pieces.push_back({s, data_offset[s] + (int64_t)(lo - b0), st + (lo - w0), hi - lo, hi == b1});
+                // the alignment gap behind the stream (up to kGapFill bytes to the next stream's start) is a
+                // piece of its own, filled with zeros -- in whichever window(s) it falls
+                size_t g1 = b1;
+                if (s + 1 < n) {
+                    const size_t nb0 = (size_t)stream_offset[s + 1] * 2;
+                    if (nb0 > b1 && nb0 - b1 <= kUploadGapFill) g1 = nb0;
+                }
+                if (g1 <= w0) { s_cur = s + 1; continue; }
+                if (b1 > w0) {
+                    const size_t lo = std::max(b0, w0), hi = std::min(b1, w1);
+                    if (hi > lo) pieces.push_back({s, data_offset[s] + (int64_t)(lo - b0), st + (lo - w0), hi - lo, hi == b1});
+                }
+                const size_t zlo = std::max(b1, w0), zhi = std::min(g1, w1);
+                if (zhi > zlo) pieces.push_back({kZeroPiece, 0, st + (zlo - w0), zhi - zlo, false});
             }
             parallel_for(pieces.size(), io_threads(), [&](size_t i) {
                 const Piece& p = pieces[i];
+                if (p.file == kZeroPiece) { std::memset(p.dst, 0, p.bytes); return; }
                 if (fds[p.file] < 0) fds[p.file] = open(paths[p.file], O_RDONLY | O_CLOEXEC);
                 if (fds[p.file] < 0 || !pread_all(fds[p.file], p.dst, p.bytes, p.file_off))
                     io_failed.store((int)p.file);
@@ -1101,13 +1115,11 @@ static int wav_upload_impl(const char* const* paths, const int64_t* data_offset,
             // the run (one copy per stream would cost more than the transfer); a larger gap -- room the
             // caller keeps for streams it fills some other way -- ends the run and is never written.
             {
-                constexpr size_t kGapFill = 256;
                 size_t run0 = 0, run1 = 0;                              // window-relative byte range of the open run
                 bool open = false;
                 for (const Piece& p : pieces) {
                     const size_t a0 = (size_t)(p.dst - st), a1 = a0 + p.bytes;
-                    if (open && a0 - run1 <= kGapFill) {
-                        if (a0 > run1) std::memset(st + run1, 0, a0 - run1);
+                    if (open && a0 == run1) {                           // (gaps to be zeroed are pieces themselves)
                         run1 = a1;
                         continue;
                     }
@@ -1216,7 +1228,11 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
     {
         size_t w_b0 = 0, w_b1 = 0;                    // open window's device byte range
         bool open_w = false;
-        auto close_window = [&] { if (open_w) { wins.push_back({w_b0, w_b1 - w_b0}); open_w = false; } };
+        size_t last_end = 0;                          // device byte where the last closed window ended
+        bool have_end = false;
+        auto close_window = [&] {
+            if (open_w) { wins.push_back({w_b0, w_b1 - w_b0}); open_w = false; last_end = w_b1; have_end = true; }
+        };
         // the first windows are SMALL (1, 2, 4 ... MiB up to the full window): the first transfer starts after a
         // fraction of a millisecond of file reading instead of after a whole 16 MiB of it
         auto win_cap = [&] { return std::min(kWindow, ((size_t)1 << 20) << std::min<size_t>(wins.size(), 6)); };
@@ -1232,7 +1248,13 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
                 const size_t p0 = b0 + done;
                 const size_t wcap = win_cap();
                 if (open_w && (p0 > w_b1 + kGapFill || p0 - w_b0 >= wcap)) close_window();
-                if (!open_w) { w_b0 = w_b1 = p0; open_w = true; }
+                if (!open_w) {
+                    // a small alignment gap behind the previous window's last slot becomes the head of this one
+                    // (the sender zero-fills everything of a window that no piece covers)
+                    w_b0 = (have_end && p0 > last_end && p0 - last_end <= kGapFill) ? last_end : p0;
+                    w_b1 = p0;
+                    open_w = true;
+                }
                 const size_t wcap2 = win_cap();       // (closing a window may have moved on to a larger one)
                 const size_t room = wcap2 - (p0 - w_b0);
                 const size_t take = std::min(cap - done, room);
@@ -1375,6 +1397,7 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
                 if (pc.stage_off > cur) std::memset(st + cur, 0, pc.stage_off - cur);
                 cur = std::max(cur, pc.stage_off + pc.bytes);
             }
+            if (cur < wins[w].bytes) std::memset(st + cur, 0, wins[w].bytes - cur);   // (a window that is all gap)
             // windows alternate between two copy streams (disjoint device ranges: no order needed between them),
             // so the next transfer is already queued when one ends
             hipStream_t cs = copy_stream[w & 1];

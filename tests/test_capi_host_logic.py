@@ -1,0 +1,213 @@
+"""CPU tests of the C-ABI's HOST logic that normally needs a GPU to run at all: the staging ring of
+afsk_wav_ingest (pool threads filling, the caller sending, buffers handed back when a copy completes), the
+window packing of afsk_wav_upload / afsk_demod_streams_host, scratch leases under concurrent callers, the
+group plan.  afsk_capi.hip is compiled AS IS and linked, for this test only, against a fake HIP runtime
+(tests/helpers/hip_stub_runtime.cpp: device memory = host memory, every stream an in-order worker thread, so
+copies are really asynchronous) and stub kernel launchers -- so "device" buffers are numpy arrays whose
+contents can be checked byte for byte against the stdlib `wave` reader the reference calls (afskmodem.py:214).
+tools/capi_asan.sh runs this file again against ThreadSanitizer and AddressSanitizer builds (AFSK_STUB_LIB).
+Nothing here is a product path: the product library fails loudly without a device (tests/test_host_api.py)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+import wave
+
+import numpy as np
+import pytest
+
+from afskmodem_amd import _native
+from tests.golden_inputs import build_riff
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERN = 0x5A5A
+
+
+@pytest.fixture(scope="module")
+def stub(tmp_path_factory):
+    path = os.environ.get("AFSK_STUB_LIB")
+    if not path:
+        path = str(tmp_path_factory.mktemp("stub") / "libafsk_stub.so")
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "helpers", "build_stub_lib.sh"), path])
+    os.environ.setdefault("AFSK_INGEST_WINDOW_MB", "4")      # small windows: a 9 MB file spans three of them
+    os.environ.setdefault("AFSK_INGEST_SLOTS", "3")          # a short ring: buffers are reused many times
+    os.environ.setdefault("AFSK_IO_THREADS", "6")
+    L = C.CDLL(path)
+    for name, (res, args) in _native.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    assert L.afsk_device_count() == 1                        # the fake runtime, not a GPU
+    return L
+
+
+def _canonical(path, n_bytes, seed):
+    data = np.random.default_rng(seed).integers(0, 256, n_bytes, dtype=np.uint8).tobytes()
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(48000)
+        f.writeframes(data[: n_bytes & ~1])
+    return path
+
+
+def _files(tmp_path):
+    """Canonical files of many sizes (one larger than two staging windows), files with other chunks before
+    'data' (the general chunk walk), an odd data size, an empty data chunk, and things that are not RIFF."""
+    names = []
+    sizes = [0, 2, 96000, 96000, 4096, 123456, 9_000_002, 70000, 1 << 20, 96000, 3_000_000, 500, 96000, 4_194_304 - 44]
+    for i, n in enumerate(sizes):
+        names.append(str(_canonical(tmp_path / f"c{i:02d}.wav", n, i)))
+    fmt = {"tag": 1, "channels": 1, "rate": 48000, "bits": 16}
+    extra = [
+        {"magic": "RIFF", "form": "WAVE", "riff_size": "auto",
+         "chunks": [["LIST", "hex", "00" * 26, None], ["fmt ", "fmt", fmt, None], ["data", "pattern", 50001, None]]},
+        {"magic": "RIFF", "form": "WAVE", "riff_size": "auto",
+         "chunks": [["fmt ", "fmt", {**fmt, "channels": 2}, None], ["fact", "hex", "01020304", None], ["data", "pattern", 7778, None]]},
+        {"magic": "RIFF", "form": "WAVE", "riff_size": "auto", "chunks": [["fmt ", "fmt", fmt, None]]},          # no data chunk
+        {"magic": "RIFX", "form": "WAVE", "riff_size": "auto", "chunks": [["fmt ", "fmt", fmt, None], ["data", "pattern", 100, None]]},
+    ]
+    for i, r in enumerate(extra):
+        fn = tmp_path / f"x{i}.wav"
+        fn.write_bytes(build_riff(r))
+        names.append(str(fn))
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not a wav file at all" * 50)
+    names += [str(junk), str(tmp_path / "missing.wav")]
+    # interleave so that windows mix kinds
+    order = np.random.default_rng(5).permutation(len(names))
+    return [names[i] for i in order]
+
+
+def _reference_bytes(fn):
+    try:
+        with wave.open(fn, "rb") as f:
+            raw = f.readframes(f.getnframes())
+        return raw[: len(raw) & ~1]
+    except Exception:  # noqa: BLE001  (wave.Error, EOFError, FileNotFoundError: not a plain PCM RIFF file)
+        return None
+
+
+def _c_paths(names):
+    enc = [os.fsencode(n) for n in names]
+    return enc, (C.c_char_p * len(enc))(*enc)
+
+
+def p64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def test_ingest_ring_delivers_every_file_exactly(stub, tmp_path):
+    names = _files(tmp_path)
+    n = len(names)
+    keep, arr = _c_paths(names)
+    sizes = np.zeros(n, np.int64)
+    assert stub.afsk_file_sizes(arr, n, p64(sizes)) == 0
+    slot = ((np.maximum(sizes, 0) // 2) + 7) & ~np.int64(7)
+    offs = np.zeros(n, np.int64)
+    gaps = np.random.default_rng(9).choice([0, 8, 64, 128, 4096], n)          # <= 128 samples = 256 B: zero-filled; larger: untouched
+    offs[1:] = np.cumsum(slot[:-1] + gaps[:-1])
+    total = int(offs[-1] + slot[-1]) + 1000
+    for rep in range(3):                                                       # the ring's buffers and events are reused across calls
+        dev = np.full(total, PATTERN, np.int16)
+        d_off, d_bytes, status = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        rc = stub.afsk_wav_ingest(arr, n, p64(offs), p64(slot), dev.ctypes.data, total, p64(d_off), p64(d_bytes), p32(status))
+        assert rc == 0, rc
+        covered = np.zeros(total, bool)
+        for i, fn in enumerate(names):
+            want = _reference_bytes(fn)
+            lo, hi = int(offs[i]), int(offs[i] + slot[i])
+            covered[lo:hi] = True
+            got = dev[lo:hi].tobytes()
+            if want is None:
+                assert status[i] != 0, fn
+                assert got == bytes(len(got)), fn                              # a zeroed slot for the caller's fallback
+                continue
+            assert status[i] == 0 and int(d_bytes[i]) & ~1 == len(want), (fn, status[i], d_bytes[i], len(want))
+            assert got[: len(want)] == want, fn
+            assert got[len(want):] == bytes(len(got) - len(want)), fn          # the rest of the slot: zeros
+            if i + 1 < n and 0 < gaps[i] <= 128:
+                covered[hi: hi + int(gaps[i])] = True
+                assert not dev[hi: hi + int(gaps[i])].any(), fn                # small alignment gaps travel as zeros
+        assert (dev[~covered] == PATTERN).all()                                # nothing else is written
+
+
+def test_two_call_upload_matches_the_one_pass_ingest(stub, tmp_path):
+    names = [fn for fn in _files(tmp_path) if _reference_bytes(fn) is not None]
+    n = len(names)
+    keep, arr = _c_paths(names)
+    d_off, d_bytes, status = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+    assert stub.afsk_wav_probe(arr, n, p64(d_off), p64(d_bytes), p32(status)) == 0 and (status == 0).all()
+    lens = d_bytes // 2
+    gaps = np.random.default_rng(11).choice([0, 3, 7, 128, 129, 5000], n)    # samples: <= 128 (256 B) zero-filled, more untouched
+    offs = np.zeros(n, np.int64)
+    offs[1:] = np.cumsum(lens[:-1] + gaps[:-1])
+    total = int(offs[-1] + lens[-1])
+    dev = np.full(total + 64, PATTERN, np.int16)
+    assert stub.afsk_wav_upload(arr, p64(d_off), p64(d_bytes), p64(offs), n, dev.ctypes.data, total + 64) == 0
+    covered = np.zeros(total + 64, bool)
+    for i, fn in enumerate(names):
+        want = _reference_bytes(fn)
+        lo, hi = int(offs[i]), int(offs[i] + lens[i])
+        assert dev[lo:hi].tobytes() == want, fn
+        covered[lo:hi] = True
+        if i + 1 < n and 0 < gaps[i] <= 128:
+            assert not dev[hi: hi + int(gaps[i])].any(), (fn, gaps[i])          # alignment gaps travel as zeros,
+            covered[hi: hi + int(gaps[i])] = True                              # wherever a window boundary falls
+    assert (dev[~covered] == PATTERN).all()                                    # larger gaps and the rest: untouched
+
+
+def test_host_entries_from_concurrent_threads(stub):
+    """afsk_demod_streams_host / afsk_demod_batch_host from four threads at once (one shared scratch cache with a
+    blocking and a non-blocking lease, pinned windows, per-thread streams): every call returns OK (the kernel
+    launch is a stub: outputs stay zero) -- the point is the lock and buffer discipline under the sanitizers."""
+    rng = np.random.default_rng(3)
+    errs = []
+
+    def work(k):
+        try:
+            for rep in range(4):
+                n = 40 + 7 * k + rep
+                arrs = [rng.integers(-3000, 3000, int(m)).astype(np.int16) for m in rng.integers(0, 300000, n)]
+                lens = np.array([a.size for a in arrs], np.int32)
+                bf = np.where(np.arange(n) % 3 == 0, 40, 160).astype(np.int32) if k % 2 else np.full(n, 40, np.int32)
+                ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+                ob = np.zeros((n, 8), np.uint8)
+                i32 = [np.zeros(n, np.int32) for _ in range(5)]
+                rc = stub.afsk_demod_streams_host(ptrs, p32(lens), p32(bf), 14000, n, ob.ctypes.data_as(C.POINTER(C.c_uint8)), 8,
+                                                  *(p32(a) for a in i32))
+                assert rc == 0, rc
+                flat = np.concatenate(arrs) if n else np.zeros(1, np.int16)
+                offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+                rc = stub.afsk_demod_batch_host(flat.ctypes.data_as(C.POINTER(C.c_int16)), flat.size, p64(offs), p32(lens), p32(bf),
+                                                14000, n, ob.ctypes.data_as(C.POINTER(C.c_uint8)), 8, *(p32(a) for a in i32))
+                assert rc == 0, rc
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert stub.afsk_host_scratch_release() == 0
+
+
+def test_group_plan_buckets(stub):
+    bf = np.array([40, 160, 40, 20, 7, 160, 40, 0, 128, 500, 40, 4096], np.int32)
+    h = C.c_void_p()
+    assert stub.afsk_group_plan_create(p32(bf), bf.size, C.byref(h)) == 0 and h
+    ng, nn = C.c_int32(), C.c_int32()
+    assert stub.afsk_group_plan_info(h, C.byref(nn), C.byref(ng), None, None, 0) == 0
+    gb, gc = (C.c_int32 * ng.value)(), (C.c_int32 * ng.value)()
+    assert stub.afsk_group_plan_info(h, None, None, gb, gc, ng.value) == 0
+    groups = list(zip(gb, gc))
+    assert nn.value == 12 and groups[0] == (40, 4) and groups[1] == (160, 2) and groups[-1] == (0, 3)
+    assert sorted(groups[2:-1]) == [(20, 1), (128, 1), (500, 1)]
+    tail = (None, None, None, 14000, None, 0, None, None, None, None, None, None, None, 0, None)
+    assert stub.afsk_demod_batch_grouped(h, *tail) == _native.E_INVALID_ARG        # null pointers are still refused
+    x = np.zeros(64, np.int16); off = np.zeros(12, np.int64); ln = np.zeros(12, np.int32)
+    i32 = [np.zeros(12, np.int32) for _ in range(5)]
+    assert stub.afsk_demod_batch_grouped(h, x.ctypes.data, off.ctypes.data, ln.ctypes.data, 14000, None, 0,
+                                         *(a.ctypes.data for a in i32), None, None, 0, None) == 0
+    assert stub.afsk_group_plan_destroy(h) == 0

@@ -48,3 +48,14 @@ ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
 [t.start() for t in ts]; [t.join() for t in ts]
 print("tsan pass ok (any report would have ended the process with code 66)")
 PY
+# r4: the GPU-needing host entries (afsk_wav_ingest's staging ring, afsk_wav_upload, the host-buffer entries, the
+# group plan) against the fake HIP runtime of tests/helpers/ -- asynchronous copies on worker threads, so a staging
+# buffer reused before its copy ran is a race TSan reports -- under ThreadSanitizer and AddressSanitizer
+for san in thread address,undefined; do
+  tag=${san%%,*}
+  bash "$ROOT/tests/helpers/build_stub_lib.sh" "$W/libafsk_stub_$tag.so" -fsanitize=$san -fno-omit-frame-pointer
+  case $tag in thread) RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1);;
+               *) RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1);; esac
+  TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT \
+    AFSK_STUB_LIB="$W/libafsk_stub_$tag.so" python -m pytest tests/test_capi_host_logic.py -q -p no:cacheprovider
+done
