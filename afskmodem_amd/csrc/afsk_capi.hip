@@ -270,9 +270,11 @@ public:
         done_cv_.wait(lk, [&] { return busy_ == 0; });
         fn_ = nullptr;
     }
-    // body(i) for i in [0, n) on up to `width` POOL threads while the caller runs main_fn() (a coordinator
-    // that consumes what the workers produce); returns when both are done.  If no pool thread could be
-    // started the caller runs the tasks itself after main_fn() -- main_fn must cope with that (it is told).
+    // body(i) for i in [0, n) on POOL threads only (at least `width` of them exist afterwards, thread creation
+    // permitting) while the caller runs main_fn(have_workers) -- a coordinator that consumes what the workers
+    // produce; returns when both are done.  When no pool thread could be started main_fn is told so
+    // (have_workers == false) and has to run the tasks itself: run_split never does.  One job at a time:
+    // job_mu_ is held for the whole call, so a concurrent run() / run_split() of another thread waits.
     template <class F, class M>
     void run_split(size_t n, unsigned width, F&& body, M&& main_fn) {
         std::lock_guard<std::mutex> job_lock(job_mu_);

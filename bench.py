@@ -1220,7 +1220,9 @@ def run_rank(args) -> None:
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
-        path = write_full_record(out, world, args.workload)
+        # only the default run (headline + every rider) writes bench_full_n<N>.json; side runs get their own file
+        tag = args.workload or ("partial" if (args.sub is not None or args.streams) else "")
+        path = write_full_record(out, world, tag)
         print(json.dumps(compact_line(out, path)), flush=True)
 
 

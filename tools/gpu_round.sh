@@ -2,13 +2,15 @@
 # One GPU visit: parity tests, smoke, the bench line (N = 1: config5 headline + sub-records config2/3/4
 # + f1/f2/f3), and with "prof" rocprofv3 kernel trace + PMC passes (FETCH_SIZE and WRITE_SIZE in
 # separate runs) for the workloads listed in PROF_WL.  Outputs under gpurun_out/.
-#   bash tools/gpu_round.sh [prof] [tag]
+#   [SKIP_TESTS=1] [PROF_WL="config5 config2 custom375,160"] bash tools/gpu_round.sh [prof] [tag]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 export PROF_TAG=${2:-r3}
 T=$PROF_TAG
+if [ -z "${SKIP_TESTS:-}" ]; then
 ( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/${T}_pytest_gpu.log
+fi
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) | tee gpurun_out/${T}_smoke.log
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/${T}_bench_main.err | grep '^{"metric"' ) > gpurun_out/${T}_bench_main.json
 cut -c1-600 gpurun_out/${T}_bench_main.json
