@@ -12,6 +12,34 @@ from __future__ import annotations
 import numpy as np
 
 
+def bind_to_device_numa_node(device=None):
+    """One process per GPU belongs on the socket its GPU hangs off: confine the calling thread (and every thread
+    it starts afterwards -- the library's I/O pool, torch's workers) to the CPUs of the NUMA node closest to
+    ``device`` (default: the current one).  On the two-socket MI355X hosts a pinned buffer on the other socket is
+    read across the inter-socket link (43 instead of 57 GB/s host -> device) and page-cache copies run at half the
+    rate.  Returns {"node", "cpus"} or None when the node cannot be found out (then nothing is changed)."""
+    import os
+    import torch
+    try:
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+        pr = torch.cuda.get_device_properties(idx)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"node": node, "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
 def shard_range(n_streams: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous, balanced [begin, end) of rank's streams."""
     return (n_streams * rank) // world, (n_streams * (rank + 1)) // world

@@ -219,6 +219,9 @@ class Ctx:
         dev_index = 0 if args.share_gpu0 else self.local_rank
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
+        # one process per GPU, on the socket its GPU hangs off (host side of the PCIe traffic: f3, host entries)
+        from afskmodem_amd import dist as adist
+        self.numa = adist.bind_to_device_numa_node(self.dev)
         self.use_dist = self.world > 1 or args.force_gather
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -887,7 +890,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                             "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
                                           "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
                                           "(page cache warm: the files were just written)" % reps},
-               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "files_on": d.split(os.sep)[1] if os.sep in d else d}
+               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "numa_binding": ctx.numa, "files_on": d.split(os.sep)[1] if os.sep in d else d}
         del pin, devbuf
         return rec
     finally:

@@ -71,6 +71,8 @@ extern "C" {
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int*, hipDeviceAttribute_t, int) { return hipErrorInvalidValue; }   // NUMA node unknown:
+hipError_t hipDeviceGetPCIBusId(char*, int, int) { return hipErrorInvalidValue; }                    // no binding
 const char* hipGetErrorString(hipError_t) { return "stub runtime error"; }
 hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
