@@ -1339,7 +1339,13 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
         for (size_t s = 0; s < n; s++) {
             const size_t b0 = (size_t)slot_offset[s] * 2, cap = (size_t)slot_samples[s] * 2;
             if (cap == 0) {                           // nothing to copy, but the file is still probed
-                if (!open_w) { w_b0 = w_b1 = b0; open_w = true; }
+                // (an empty slot is a slot: a small gap in front of it travels as zeros like any other)
+                if (open_w && b0 > w_b1 && b0 - w_b1 <= kGapFill && b0 - w_b0 <= win_cap()) w_b1 = b0;
+                if (!open_w) {
+                    w_b0 = (have_end && b0 > last_end && b0 - last_end <= kGapFill) ? last_end : b0;
+                    w_b1 = b0;
+                    open_w = true;
+                }
                 pieces.push_back({s, wins.size(), 0, 0, 0});
                 continue;
             }
@@ -1413,24 +1419,22 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
                 unsigned char hdr[44];
                 struct iovec iov[2] = {{hdr, sizeof hdr}, {dst, cap}};
                 const ssize_t got = preadv(fd, iov, 2, 0);
+                struct stat sb;
+                // the read is trusted only if it returned everything the file holds up to the end of the slot
+                // (a short read that is not the end of the file -- POSIX allows it -- takes the general walk)
                 if (got >= 44 && std::memcmp(hdr, "RIFF", 4) == 0 && std::memcmp(hdr + 8, "WAVEfmt ", 8) == 0 &&
-                    le32(hdr + 16) == 16 && std::memcmp(hdr + 36, "data", 4) == 0) {
+                    le32(hdr + 16) == 16 && std::memcmp(hdr + 36, "data", 4) == 0 && fstat(fd, &sb) == 0 &&
+                    (int64_t)got == std::min<int64_t>((int64_t)sb.st_size, 44 + (int64_t)cap)) {
                     const uint32_t tag = le16(hdr + 20), channels = le16(hdr + 22), width = (le16(hdr + 34) + 7) / 8;
                     const int64_t framesize = (int64_t)channels * width;
                     const int64_t csize = (int64_t)le32(hdr + 40);
-                    const int64_t fsize_min = 44 + (int64_t)(got - 44);          // bytes the file is known to hold
-                    // the file ended inside what we asked for (short read), or holds exactly header + slot: its size is known
-                    const bool size_known = (size_t)(got - 44) < cap || fsize_min == (int64_t)(44 + cap);
-                    if (tag == 1 && framesize > 0 && size_known) {
-                        struct stat sb;
-                        int64_t fsize = fsize_min;
-                        if ((size_t)(got - 44) == cap && fstat(fd, &sb) == 0) fsize = (int64_t)sb.st_size;
-                        const int64_t form_end = std::min<int64_t>(fsize, 8 + (int64_t)le32(hdr + 4));
-                        const int64_t want = (csize / framesize) * framesize;
+                    if (tag == 1 && framesize > 0) {
+                        const int64_t form_end = std::min<int64_t>((int64_t)sb.st_size, 8 + (int64_t)le32(hdr + 4));
+                        const int64_t want = (csize / framesize) * framesize;          // getnframes() whole frames
                         const int64_t avail = std::max<int64_t>(0, form_end - 44);
                         doff = 44; dbytes = std::min(want, avail);
                         const size_t usable = (size_t)dbytes & ~(size_t)1;
-                        if (usable <= cap && usable <= (size_t)(got - 44)) {
+                        if (usable <= cap && 44 + (int64_t)usable <= (int64_t)got) {
                             st = AFSK_WAV_OK;
                             have_data = true;
                             out_data_offset[pc.file] = doff; out_data_bytes[pc.file] = dbytes; out_status[pc.file] = st;

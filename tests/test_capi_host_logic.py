@@ -68,6 +68,15 @@ def _files(tmp_path):
         fn = tmp_path / f"x{i}.wav"
         fn.write_bytes(build_riff(r))
         names.append(str(fn))
+    # canonical 44-byte header whose data size promises more than the file holds / whose RIFF size clips the data
+    import struct
+    body = bytes(range(256)) * 3
+    hdr = lambda riff, dsz: (b"RIFF" + struct.pack("<L", riff) + b"WAVEfmt " + struct.pack("<LHHLLHH", 16, 1, 1, 48000, 96000, 2, 16)
+                             + b"data" + struct.pack("<L", dsz))  # noqa: E731
+    (tmp_path / "trunc.wav").write_bytes(hdr(36 + 5000, 5000) + body)            # 768 of 5000 promised bytes
+    (tmp_path / "clip.wav").write_bytes(hdr(36 + 300, 768) + body)              # the RIFF form ends inside the data
+    (tmp_path / "odd.wav").write_bytes(hdr(36 + 767, 767) + body[:767] + b"\x00")
+    names += [str(tmp_path / "trunc.wav"), str(tmp_path / "clip.wav"), str(tmp_path / "odd.wav")]
     junk = tmp_path / "junk.wav"
     junk.write_bytes(b"not a wav file at all" * 50)
     names += [str(junk), str(tmp_path / "missing.wav")]
@@ -120,6 +129,9 @@ def test_ingest_ring_delivers_every_file_exactly(stub, tmp_path):
             lo, hi = int(offs[i]), int(offs[i] + slot[i])
             covered[lo:hi] = True
             got = dev[lo:hi].tobytes()
+            if i + 1 < n and 0 < gaps[i] <= 128:                               # small alignment gaps travel as zeros --
+                covered[hi: hi + int(gaps[i])] = True                          # behind ANY slot, also an empty or refused one
+                assert not dev[hi: hi + int(gaps[i])].any(), fn
             if want is None:
                 assert status[i] != 0, fn
                 assert got == bytes(len(got)), fn                              # a zeroed slot for the caller's fallback
@@ -127,10 +139,27 @@ def test_ingest_ring_delivers_every_file_exactly(stub, tmp_path):
             assert status[i] == 0 and int(d_bytes[i]) & ~1 == len(want), (fn, status[i], d_bytes[i], len(want))
             assert got[: len(want)] == want, fn
             assert got[len(want):] == bytes(len(got) - len(want)), fn          # the rest of the slot: zeros
-            if i + 1 < n and 0 < gaps[i] <= 128:
-                covered[hi: hi + int(gaps[i])] = True
-                assert not dev[hi: hi + int(gaps[i])].any(), fn                # small alignment gaps travel as zeros
         assert (dev[~covered] == PATTERN).all()                                # nothing else is written
+
+
+def test_ingest_slot_too_small_is_that_files_problem(stub, tmp_path):
+    """A slot smaller than the file's data: status AFSK_WAV_SLOT and a zeroed slot for that file (the Python host
+    then falls back to the stdlib reader), the neighbours are delivered."""
+    names = [str(_canonical(tmp_path / f"s{i}.wav", 40000 + 2 * i, 50 + i)) for i in range(5)]
+    keep, arr = _c_paths(names)
+    slot = np.array([20000 + i + 7 & ~7 for i in range(5)], np.int64)
+    slot[2] = 8000                                                             # 16000 B for 40004 B of data
+    offs = np.zeros(5, np.int64)
+    offs[1:] = np.cumsum(slot[:-1])
+    total = int(offs[-1] + slot[-1])
+    dev = np.full(total, PATTERN, np.int16)
+    d_off, d_bytes, status = np.zeros(5, np.int64), np.zeros(5, np.int64), np.zeros(5, np.int32)
+    assert stub.afsk_wav_ingest(arr, 5, p64(offs), p64(slot), dev.ctypes.data, total, p64(d_off), p64(d_bytes), p32(status)) == 0
+    assert list(status) == [0, 0, _native.WAV_SLOT, 0, 0] and d_bytes[2] == 40004
+    assert not dev[int(offs[2]): int(offs[2] + slot[2])].any()
+    for i in (0, 1, 3, 4):
+        want = _reference_bytes(names[i])
+        assert dev[int(offs[i]): int(offs[i]) + len(want) // 2].tobytes() == want
 
 
 def test_two_call_upload_matches_the_one_pass_ingest(stub, tmp_path):
