@@ -73,6 +73,7 @@ SIGNATURES = {
     "afsk_file_sizes": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p]),
     "afsk_wav_ingest": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, _i64p, _i64p, C.c_void_p, C.c_int64,
                                   _i64p, _i64p, _i32p]),
+    "afsk_wav_egress": (C.c_int, [C.POINTER(C.c_char_p), C.c_int32, C.c_void_p, _i64p, _i32p, _i32p]),
     "afsk_wav_upload": (C.c_int, [C.POINTER(C.c_char_p), _i64p, _i64p, _i64p, C.c_int32, C.c_void_p,
                                   C.c_int64]),
     "afsk_modulate_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

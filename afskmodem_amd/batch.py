@@ -651,6 +651,38 @@ def load_wav_batch(filenames, device=None):
     return samples, t(offs), t(lens.astype(np.int32)), int(lens.max())
 
 
+def save_wav_batch(samples, stream_offset, stream_len, filenames) -> np.ndarray:
+    """Device streams -> .wav files (``afsk_wav_egress``; SoundOutput.writeToFile, ref:256-263, for many streams):
+    stream i of ``samples`` (an int16 CUDA tensor) is written to ``filenames[i]`` behind the canonical 44-byte
+    header.  ``stream_offset`` / ``stream_len`` are HOST arrays (or tensors, brought to the host).  Returns the
+    per-file status (0 = written)."""
+    torch = _torch()
+    _native.require_device()
+    if not (isinstance(samples, torch.Tensor) and samples.is_cuda and samples.dtype == torch.int16
+            and samples.is_contiguous()):
+        raise TypeError("samples must be a contiguous int16 CUDA tensor")
+    names = list(filenames)
+    n = len(names)
+    host = lambda a, dt: np.ascontiguousarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=dt)  # noqa: E731
+    offs, lens = host(stream_offset, np.int64), host(stream_len, np.int32)
+    if offs.size != n or lens.size != n:
+        raise ValueError(f"{n} file names for {offs.size} offsets / {lens.size} lengths")
+    status = np.zeros(n, np.int32)
+    if n == 0:
+        return status
+    if int((offs + lens).max()) > samples.numel():
+        raise ValueError("a stream reaches beyond the sample buffer")
+    keep, arr = _c_names(names)
+    # the egress reads `samples` on the library's private streams: what produced them must have finished
+    torch.cuda.current_stream(samples.device).synchronize()
+    with torch.cuda.device(samples.device):
+        _native.check(_native.lib().afsk_wav_egress(arr, n, samples.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    status.ctypes.data_as(C.POINTER(C.c_int32))))
+    del keep
+    return status
+
+
 def modulate_batch(payload, payload_len, bit_frames, ts_cycles, stream_offset, stream_len,
                    max_stream_len: int, samples, wav_quirk: bool = True, stream=None) -> None:
     """On-device Transmitter.__getFrames + .wav quirk (ref:452-469, 239-244) into ``samples``.

@@ -1567,6 +1567,206 @@ int afsk_wav_ingest(const char* const* paths, int32_t n_files, const int64_t* sl
     });
 }
 
+// ---- .wav egress at scale: device streams -> canonical RIFF/WAVE files (Transmitter.save for many payloads) ----
+// The mirror image of afsk_wav_ingest: the calling thread copies windows of the device range into the pinned
+// staging ring (D2H, two alternating streams) and hands every window to the pool as soon as its copy has
+// completed; pool threads write the file pieces of the window -- one open / pwritev (header + data) / close for a
+// file that lies inside one window -- and a staging buffer is reused once all its pieces are on their way.
+static int wav_egress_impl(const char* const* paths, int32_t n_files, const int16_t* d_samples,
+                           const int64_t* stream_offset, const int32_t* stream_len, int32_t* out_status) {
+    if (n_files < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
+    if (n_files == 0) return AFSK_OK;
+    if (!paths || !d_samples || !stream_offset || !stream_len || !out_status)
+        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    const size_t n = (size_t)n_files;
+    int64_t prev_end = 0;
+    for (size_t s = 0; s < n; s++) {
+        if (!paths[s] || stream_len[s] < 0 || stream_offset[s] < prev_end)
+            return fail(AFSK_E_INVALID_ARG, "streams must be ascending and must not overlap");
+        if ((int64_t)stream_len[s] > (int64_t)((0xFFFFFFFFll - 36) / 2))
+            return fail(AFSK_E_INVALID_ARG, "a stream too long for a RIFF file");
+        prev_end = stream_offset[s] + stream_len[s];
+    }
+    if (int rc0 = require_device()) return rc0;
+    {
+        cpu_set_t cpus;
+        if (device_node_cpus(&cpus)) io_pool().confine_to(cpus);
+    }
+    static const size_t kWindow = (size_t)16 << 20;
+    static const int kSlots = 8;
+    int rc = AFSK_OK;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    {
+        hipError_t e = g_thread_stream.get(&copy_stream[0]);
+        if (e == hipSuccess) e = g_thread_stream2.get(&copy_stream[1]);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry streams)");
+    }
+    ScratchLease lease;
+    char* d_unused = nullptr;
+    char* stage[kMaxRingSlots];
+    hipEvent_t landed_ev[kMaxRingSlots];
+    {
+        hipError_t e = lease.acquire(1, &d_unused, /*block=*/true);    // owns the staging ring
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-entry scratch)");
+        e = lease.ring(kWindow, kSlots, stage, landed_ev);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc / hipEventCreate (staging ring)");
+    }
+    // windows over the device byte range; a gap of more than 64 KiB between two streams is not copied
+    struct Piece { size_t file; size_t win; size_t lo; size_t bytes; size_t stage_off; bool whole; };
+    struct Window { size_t dev_b0; size_t bytes; };
+    std::vector<Piece> pieces;
+    std::vector<Window> wins;
+    pieces.reserve(n + 8);
+    {
+        constexpr size_t kGapCopy = (size_t)64 << 10;
+        size_t w_b0 = 0, w_b1 = 0;
+        bool open_w = false;
+        auto close_window = [&] { if (open_w) { wins.push_back({w_b0, w_b1 - w_b0}); open_w = false; } };
+        auto win_cap = [&] { return std::min(kWindow, ((size_t)1 << 20) << std::min<size_t>(wins.size(), 6)); };
+        for (size_t s = 0; s < n; s++) {
+            const size_t b0 = (size_t)stream_offset[s] * 2, total = (size_t)stream_len[s] * 2;
+            if (total == 0) {                         // an empty stream still becomes a (header-only) file
+                if (!open_w) { w_b0 = w_b1 = b0; open_w = true; }
+                pieces.push_back({s, wins.size(), 0, 0, 0, true});
+                continue;
+            }
+            size_t done = 0;
+            while (done < total) {
+                const size_t p0 = b0 + done;
+                if (open_w && (p0 > w_b1 + kGapCopy || p0 - w_b0 >= win_cap())) close_window();
+                if (!open_w) { w_b0 = w_b1 = p0; open_w = true; }
+                const size_t cap = win_cap();
+                const size_t room = cap - (p0 - w_b0);
+                const size_t take = std::min(total - done, room);
+                if (take < total - done && done == 0 && total <= cap && p0 != w_b0) { close_window(); continue; }
+                pieces.push_back({s, wins.size(), done, take, p0 - w_b0, take == total});
+                done += take;
+                w_b1 = p0 + take;
+                if (w_b1 - w_b0 >= cap) close_window();
+            }
+        }
+        close_window();
+    }
+    const size_t nwin = wins.size(), npieces = pieces.size();
+    std::vector<std::atomic<int>> remaining(std::max<size_t>(nwin, 1));
+    for (auto& r : remaining) r.store(0);
+    for (const Piece& pc : pieces) if (pc.win < nwin) remaining[pc.win].fetch_add(1);
+    for (size_t s = 0; s < n; s++) out_status[s] = AFSK_WAV_OK;
+    std::mutex hand_mu;
+    std::condition_variable cv_landed, cv_written;
+    long landed = 0;                                        // windows whose D2H copy has completed
+    std::atomic<int> failed{0};
+
+    auto header = [](unsigned char* h, uint32_t data_bytes) {   // what wave.Wave_write emits for 1 ch / 16 bit / 48000 Hz
+        auto p32 = [](unsigned char* q, uint32_t v) { q[0] = (unsigned char)v; q[1] = (unsigned char)(v >> 8); q[2] = (unsigned char)(v >> 16); q[3] = (unsigned char)(v >> 24); };
+        auto p16 = [](unsigned char* q, uint32_t v) { q[0] = (unsigned char)v; q[1] = (unsigned char)(v >> 8); };
+        std::memcpy(h, "RIFF", 4); p32(h + 4, 36u + data_bytes); std::memcpy(h + 8, "WAVEfmt ", 8); p32(h + 16, 16u);
+        p16(h + 20, 1u); p16(h + 22, 1u); p32(h + 24, AFSK_SAMPLE_RATE); p32(h + 28, AFSK_SAMPLE_RATE * 2u); p16(h + 32, 2u);
+        p16(h + 34, 16u); std::memcpy(h + 36, "data", 4); p32(h + 40, data_bytes);
+    };
+    auto write_piece = [&](size_t i) {
+        const Piece& pc = pieces[i];
+        if (pc.win < nwin) {
+            std::unique_lock<std::mutex> lk(hand_mu);
+            cv_landed.wait(lk, [&] { return (long)pc.win < landed || failed.load(std::memory_order_relaxed); });
+        }
+        if (!failed.load(std::memory_order_relaxed)) {
+            const uint32_t total = (uint32_t)stream_len[pc.file] * 2u;
+            // a file inside one window: create + truncate with the open; a file in several pieces: every piece sets the
+            // final size (the pieces of neighbouring windows are written concurrently, in any order)
+            const int fd = open(paths[pc.file], O_WRONLY | O_CREAT | O_CLOEXEC | (pc.whole ? O_TRUNC : 0), 0666);
+            bool ok = fd >= 0;
+            if (ok && !pc.whole) ok = ftruncate(fd, (off_t)(44 + (int64_t)total)) == 0;
+            if (ok) {
+                unsigned char hdr[44];
+                struct iovec iov[2];
+                int niov = 0;
+                int64_t off = 44 + (int64_t)pc.lo;
+                if (pc.lo == 0) { header(hdr, total); iov[niov++] = {hdr, sizeof hdr}; off = 0; }
+                if (pc.bytes > 0) iov[niov++] = {stage[pc.win % (size_t)kSlots] + pc.stage_off, pc.bytes};
+                size_t want = (pc.lo == 0 ? 44 : 0) + pc.bytes;
+                while (ok && want > 0) {                          // pwritev may be partial
+                    const ssize_t r = pwritev(fd, iov, niov, (off_t)off);
+                    if (r <= 0) { ok = false; break; }
+                    want -= (size_t)r; off += r;
+                    size_t adv = (size_t)r;
+                    while (adv > 0 && niov > 0) {
+                        if (adv >= iov[0].iov_len) { adv -= iov[0].iov_len; iov[0] = iov[1]; niov--; }
+                        else { iov[0].iov_base = (char*)iov[0].iov_base + adv; iov[0].iov_len -= adv; adv = 0; }
+                    }
+                }
+            }
+            if (fd >= 0 && close(fd) != 0) ok = false;
+            if (!ok) out_status[pc.file] = AFSK_WAV_IO;           // that file's problem; the batch goes on
+        }
+        if (pc.win < nwin && remaining[pc.win].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(hand_mu);
+            cv_written.notify_one();
+        }
+    };
+
+    hipError_t herr = hipSuccess;
+    const char* hwhat = "";
+    auto coordinator = [&](bool have_workers) {
+        size_t issued = 0, next_serial = 0;
+        for (size_t w = 0; w < nwin && herr == hipSuccess; w++) {
+            for (;;) {                                            // keep copies ahead of the writers, one per free buffer
+                if (issued >= nwin || issued >= w + (size_t)kSlots) break;
+                if (issued >= (size_t)kSlots) {
+                    const size_t dep = issued - (size_t)kSlots;   // the window whose buffer this copy reuses (dep < w: released)
+                    if (remaining[dep].load(std::memory_order_acquire) != 0) {
+                        if (issued > w) break;                    // window w itself is on its way: look again later
+                        if (!have_workers) while (next_serial < npieces && pieces[next_serial].win <= dep) write_piece(next_serial++);
+                        std::unique_lock<std::mutex> lk(hand_mu);
+                        cv_written.wait(lk, [&] { return remaining[dep].load(std::memory_order_acquire) == 0; });
+                    }
+                }
+                hipStream_t cs = copy_stream[issued & 1];
+                if (wins[issued].bytes > 0) {
+                    herr = hipMemcpyAsync(stage[issued % (size_t)kSlots], (const char*)d_samples + wins[issued].dev_b0,
+                                          wins[issued].bytes, hipMemcpyDeviceToHost, cs);
+                    hwhat = "D2H samples";
+                    if (herr != hipSuccess) break;
+                }
+                herr = hipEventRecord(landed_ev[issued % (size_t)kSlots], cs);
+                hwhat = "hipEventRecord";
+                if (herr != hipSuccess) break;
+                issued++;
+            }
+            if (herr != hipSuccess) break;
+            herr = hipEventSynchronize(landed_ev[w % (size_t)kSlots]);
+            hwhat = "hipEventSynchronize";
+            if (herr != hipSuccess) break;
+            {
+                std::lock_guard<std::mutex> lk(hand_mu);
+                landed = (long)w + 1;
+            }
+            cv_landed.notify_all();
+            if (!have_workers) while (next_serial < npieces && pieces[next_serial].win <= w) write_piece(next_serial++);
+        }
+        if (herr != hipSuccess) failed.store(1);
+        {
+            std::lock_guard<std::mutex> lk(hand_mu);
+            landed = std::numeric_limits<long>::max();
+        }
+        cv_landed.notify_all();
+        if (!have_workers) while (next_serial < npieces) write_piece(next_serial++);
+    };
+    const unsigned width = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, npieces));
+    io_pool().run_split(npieces, width, write_piece, coordinator);
+    if (herr != hipSuccess) rc = hip_fail(herr, hwhat);
+    for (int k = 0; k < 2; k++) {
+        hipError_t e = hipStreamSynchronize(copy_stream[k]);
+        if (e != hipSuccess && rc == AFSK_OK) rc = hip_fail(e, "hipStreamSynchronize");
+    }
+    return rc;
+}
+
+int afsk_wav_egress(const char* const* paths, int32_t n_files, const int16_t* d_samples,
+                    const int64_t* stream_offset, const int32_t* stream_len, int32_t* out_status) {
+    return no_throw([&] { return wav_egress_impl(paths, n_files, d_samples, stream_offset, stream_len, out_status); });
+}
+
 int afsk_modulate_batch(const uint8_t* payload, int32_t payload_stride,
                         const int32_t* payload_len, const int32_t* bit_frames,
                         const int32_t* ts_cycles, const int64_t* stream_offset,

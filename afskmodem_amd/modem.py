@@ -435,6 +435,9 @@ class Receiver:
 # --------------------------------------------------------------- Transmitter
 
 
+_MAX_STREAM_LEN = (1 << 30) - (1 << 15)      # AFSK_MAX_STREAM_LEN of the C-ABI
+
+
 class Transmitter:
     """AFSK transmitter (ref:436-484): bytes -> Hamming(7,4) -> square-wave frames."""
 
@@ -484,6 +487,48 @@ class Transmitter:
         if isinstance(data, str):
             data = data.encode("utf-8")                                    # ref:482-483
         SoundOutput.writeToFile(filename, self.frames(data))               # ref:484
+
+    def save_batch(self, data_list, filenames, device=None):
+        """``save`` for many payloads (ref:481-484 per payload): the frames of every payload are modulated on
+        the GPU with the wav writer's decimate / duplicate quirk (``afsk_modulate_batch``; ref:452-469, 239-244)
+        and written out by ``afsk_wav_egress`` -- every file byte for byte what ``save`` writes.  A baud rate the
+        device modulator has no symbol geometry for (``48000 / baud`` not a multiple of 4: the reference still
+        modulates it, the Receiver rejects it) takes the host path per file."""
+        from . import batch
+        payloads = [d.encode("utf-8") if isinstance(d, str) else bytes(d) for d in data_list]      # ref:482-483
+        names = list(filenames)
+        if len(payloads) != len(names):
+            raise ValueError(f"{len(payloads)} payloads for {len(names)} file names")
+        if not names:
+            return
+        bf = self.bit_frames
+        if bf < 4 or bf % 4 != 0 or len(self.__mark_tone) != bf or len(self.__space_tone) != bf:
+            for d, fn in zip(payloads, names):
+                self.save(d, fn)
+            return
+        import torch
+        dev = batch._default_device(device)
+        n = len(names)
+        plen = np.array([len(p) for p in payloads], np.int32)
+        stride = max(int(plen.max()), 1)
+        pay = np.zeros((n, stride), np.uint8)
+        for i, p in enumerate(payloads):
+            pay[i, : len(p)] = np.frombuffer(p, np.uint8)
+        n_frames = self.__ts_cycles * 2 * bf + 4 * bf + 14 * plen.astype(np.int64) * bf + TAIL_SILENCE   # ref:457-468
+        lens = (n_frames & ~np.int64(1)).astype(np.int32)            # ref:241: pairs (frames[i], frames[i]) for even i < n - 1
+        if int(lens.max()) > _MAX_STREAM_LEN:
+            raise ValueError("a payload too long for one stream")
+        offs = np.zeros(n, np.int64)
+        offs[1:] = np.cumsum((lens[:-1].astype(np.int64) + 7) & ~np.int64(7))
+        total = int(offs[-1] + lens[-1])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        samples = torch.empty(max(total, 1), dtype=torch.int16, device=dev)
+        batch.modulate_batch(t(pay), t(plen), t(np.full(n, bf, np.int32)), t(np.full(n, self.__ts_cycles, np.int32)),
+                             t(offs), t(lens), int(lens.max()), samples, True)
+        status = batch.save_wav_batch(samples, offs, lens, names)
+        bad = np.nonzero(status != 0)[0]
+        if bad.size:
+            self.save(payloads[int(bad[0])], names[int(bad[0])])      # raises what the stdlib writer raises for that file
 
     def wav_samples(self, data: str | bytes, total: int | None = None) -> np.ndarray:
         """The int16 samples ``save`` would put in the .wav, optionally zero padded to total."""

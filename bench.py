@@ -20,6 +20,7 @@ and so do the three built "next" rows of SURVEY 8(f), each with its own roofline
   f1_modulate    on-device modulator (write-bound, config5 shape)
   f2_gate        live-gate replay (read-bound) over 4096 and 65536 captures
   f3_wav_ingest  4096 .wav files -> device layout (PCIe-bound: against a pinned hipMemcpy of the bytes)
+  f5_wav_egress  4096 device streams -> .wav files (the mirror; against a pinned device-to-host hipMemcpy)
 plus `rates_4096` / `rates_65536`: 4096 and 65536 x 1 s at each of the 36 rates a Receiver can be built for
 (12000 ... 24 baud; the second is the steady-state fraction per rate, free of launch-shape quantisation).
 At N > 1 the config2 shard is carried as a sub-record (worst case for the per-collective cost).
@@ -75,7 +76,7 @@ WORKLOADS = {
     "custom": (4096, (1200,), None, "custom: streams x 1 s, clean, bauds from --bauds, per GPU"),
 }
 HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
-NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest")   # SURVEY 8(f) rows carried as sub-records at N = 1
+NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress")   # SURVEY 8(f) rows (+ the egress) as sub-records at N = 1
 RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
 RATES_BIG_ROW = "rates_65536"   # the same at 65536 streams: the steady-state fraction per rate (no launch-shape quantisation)
 RATES_ROWS = {RATES_ROW: 4096, RATES_BIG_ROW: 65536}
@@ -897,6 +898,59 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
+def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
+    """The mirror of f3 (r4): n streams of 1 s in device memory -> n canonical .wav files (afsk_wav_egress: D2H
+    through the pinned ring, one open / pwritev / close per file; what Transmitter.save_batch uses).
+    PCIe-bound: measured against ONE pinned device-to-host hipMemcpy of the same bytes on this box."""
+    import shutil
+    import tempfile
+    import wave
+    from afskmodem_amd import batch
+    torch = ctx.torch
+    d = tempfile.mkdtemp(prefix="afsk_bench_out_")
+    try:
+        x = torch.randint(-32768, 32767, (n_files * STREAM_LEN,), dtype=torch.int16, device=ctx.dev)
+        offs = np.arange(n_files, dtype=np.int64) * STREAM_LEN
+        lens = np.full(n_files, STREAM_LEN, np.int32)
+        names = [os.path.join(d, f"o{i:05d}.wav") for i in range(n_files)]
+        torch.cuda.synchronize()
+        assert (batch.save_wav_batch(x, offs, lens, names) == 0).all()             # warm: creates the files
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            st = batch.save_wav_batch(x, offs, lens, names)
+            ts.append(time.perf_counter() - t0)
+        total_bytes = n_files * STREAM_LEN * 2
+        pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
+        pin.copy_(x, non_blocking=True)
+        torch.cuda.synchronize()
+        pc = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pin.copy_(x, non_blocking=True)
+            torch.cuda.synchronize()
+            pc.append(time.perf_counter() - t0)
+        ok = 0
+        pick = list(range(0, n_files, max(1, n_files // 64)))
+        for i in pick:
+            with wave.open(names[i], "rb") as f:
+                raw = f.readframes(f.getnframes())
+            ok += raw == x[i * STREAM_LEN: (i + 1) * STREAM_LEN].cpu().numpy().tobytes()
+        med, peak = median(ts), total_bytes / min(pc) / 1e9
+        return {"row": "f5 .wav egress (afsk_wav_egress: device streams -> files)", "files": n_files, "bytes": total_bytes,
+                "reps": reps, "unit": "files/s", "value": round(n_files / med), "all_status_ok": bool((st == 0).all()),
+                "egress_ms": {"median": round(med * 1e3, 3), "best": round(min(ts) * 1e3, 3)},
+                "pinned_hipMemcpy_d2h_ms": round(min(pc) * 1e3, 3), "decoded_match_rate": ok / len(pick),
+                "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2), "unit": "GB/s",
+                             "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
+                             "bound_note": "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
+                                           "the egress also creates, writes (page cache) and closes every file"},
+                "files_on": d.split(os.sep)[1] if os.sep in d else d}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_streams: int = 64, warmup: int = 10) -> dict:
     """4096 x 1 s clean streams at EVERY rate a Receiver can be built for (bit_frames must divide 48000 and
     be a multiple of 4: 36 values, 12000 ... 24 baud), each through its own uniform kernel: time per launch,
@@ -1204,6 +1258,8 @@ def run_rank(args) -> None:
         torch.cuda.empty_cache()
     if world == 1 and "f3_wav_ingest" in next_rows:
         subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
+    if world == 1 and "f5_wav_egress" in next_rows:
+        subs["f5_wav_egress"] = measure_wav_egress(ctx, args.wav_files)
     for row, n_str in RATES_ROWS.items():
         if world == 1 and row in next_rows:
             big = n_str >= 32768
@@ -1237,7 +1293,7 @@ def main() -> None:
     ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
                     help="headline workload (default: config5 at every N); "
                          "giving one explicitly drops the sub-records unless --sub lists them")
-    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest,rates_4096,rates_65536 ('' = none)")
+    ap.add_argument("--sub", default=None, help="comma list of sub-records: workloads and/or f1_modulate,f2_gate,f3_wav_ingest,f5_wav_egress,rates_4096,rates_65536 ('' = none)")
     ap.add_argument("--min-region-ms", type=float, default=50.0,
                     help="repeat the K-step timed region until the regions add up to this (0 = exactly one region)")
     ap.add_argument("--entry", default="auto", choices=["auto", "mixed"],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AFSK_ABI_VERSION 2 /* 2: afsk_group_plan_* / afsk_demod_batch_grouped, AFSK_ST_BAD_LENGTH */
+#define AFSK_ABI_VERSION 2 /* 2: afsk_group_plan_* / afsk_demod_batch_grouped, AFSK_ST_BAD_LENGTH, afsk_wav_egress */
 
 /* return codes */
 #define AFSK_OK 0
@@ -270,6 +270,22 @@ int afsk_file_sizes(const char *const *paths, int32_t n_files, int64_t *out_size
 int afsk_wav_ingest(const char *const *paths, int32_t n_files, const int64_t *slot_offset,
                     const int64_t *slot_samples, int16_t *d_samples, int64_t capacity_samples,
                     int64_t *out_data_offset, int64_t *out_data_bytes, int32_t *out_status);
+
+/*
+ * .wav EGRESS at scale (r4; the mirror image of afsk_wav_ingest, for Transmitter.save, afskmodem.py:481-484, of many
+ * payloads): stream s of the device buffer, d_samples[stream_offset[s] .. + stream_len[s]), is written to paths[s] as the
+ * file SoundOutput.writeToFile (:256-263) produces through the stdlib writer -- the canonical 44-byte RIFF/WAVE header
+ * (PCM, 1 channel, 48000 Hz, 16 bit, data size 2 * stream_len[s]) followed by the samples.  (The decimate / duplicate
+ * quirk of SoundOutput.__convertFrames, :239-244, is the MODULATOR's job: afsk_modulate_batch(wav_quirk = 1).)
+ * stream_offset (samples, ascending, non-overlapping) and stream_len are HOST arrays.  The calling thread copies windows
+ * of the device range into the pinned staging ring (D2H, two alternating streams) and pool threads write each window's
+ * file pieces as soon as its copy has completed: one open / pwritev (header + data) / close per file that lies inside
+ * one window.  Existing files are replaced.  out_status[s]: AFSK_WAV_OK or AFSK_WAV_IO (cannot create / write: that
+ * file's problem, the batch goes on).  Synchronous for the caller, on the calling thread's private streams (work of the
+ * caller that still writes the source range must have completed before the call); fork-safe like the ingest.
+ */
+int afsk_wav_egress(const char *const *paths, int32_t n_files, const int16_t *d_samples,
+                    const int64_t *stream_offset, const int32_t *stream_len, int32_t *out_status);
 
 /*
  * On-device input synthesis: Transmitter.__getFrames (:452-469) with ECC.encode

@@ -91,6 +91,7 @@ def test_headline_workload_is_the_same_at_every_n():
     assert two["subs"] == ["config2"] and two["next"] == []
     # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline
     assert bench.plan(1, "config2") == {"main": "config2", "subs": [], "next": []}
+    assert "f5_wav_egress" in bench.NEXT_ROWS
     assert bench.plan(1, "custom", "config3,f2_gate") == {"main": "custom", "subs": ["config3"], "next": ["f2_gate"]}
     with pytest.raises(SystemExit):
         bench.plan(1, "f1_modulate")

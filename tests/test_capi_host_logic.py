@@ -240,3 +240,39 @@ def test_group_plan_buckets(stub):
     assert stub.afsk_demod_batch_grouped(h, x.ctypes.data, off.ctypes.data, ln.ctypes.data, 14000, None, 0,
                                          *(a.ctypes.data for a in i32), None, None, 0, None) == 0
     assert stub.afsk_group_plan_destroy(h) == 0
+
+
+def test_egress_writes_what_the_stdlib_writer_writes(stub, tmp_path):
+    """afsk_wav_egress: every file byte for byte what `wave` writes for 1 channel / 16 bit / 48000 Hz
+    (SoundOutput.writeToFile, afskmodem.py:256-263) -- streams smaller and larger than a staging window, empty
+    streams, gaps between streams, an existing longer file replaced, an unwritable path reported per file."""
+    rng = np.random.default_rng(21)
+    lens = np.array([0, 1, 48000, 48000, 5, 2_300_001, 70000, 4_194_304 // 2, 48000, 0, 1_200_000, 333, 48000], np.int32)
+    n = lens.size
+    gaps = rng.choice([0, 8, 300, 40000], n)
+    offs = np.zeros(n, np.int64)
+    offs[1:] = np.cumsum(lens[:-1].astype(np.int64) + gaps[:-1])
+    total = int(offs[-1] + lens[-1]) + 100
+    dev = rng.integers(-32768, 32768, total).astype(np.int16)
+    names = [str(tmp_path / f"o{i:02d}.wav") for i in range(n)]
+    names[6] = str(tmp_path / "no_such_dir" / "o06.wav")                       # cannot be created
+    (tmp_path / "o03.wav").write_bytes(b"x" * 500000)                          # longer than what will be written: replaced
+    (tmp_path / "o05.wav").write_bytes(b"y" * 9000000)                         # (a multi-window file: truncated, not O_TRUNC)
+    keep, arr = _c_paths(names)
+    for rep in range(2):
+        status = np.full(n, -7, np.int32)
+        assert stub.afsk_wav_egress(arr, n, dev.ctypes.data, p64(offs), p32(lens), p32(status)) == 0
+        for i in range(n):
+            if i == 6:
+                assert status[i] == 1 and not os.path.exists(names[i])         # AFSK_WAV_IO, that file only
+                continue
+            assert status[i] == 0, i
+            ref = tmp_path / "ref.wav"
+            with wave.open(str(ref), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(48000)
+                f.writeframes(dev[int(offs[i]): int(offs[i] + lens[i])].tobytes())
+            assert open(names[i], "rb").read() == ref.read_bytes(), (i, lens[i])
+    assert stub.afsk_wav_egress(arr, -1, dev.ctypes.data, p64(offs), p32(lens), p32(status)) == _native.E_INVALID_ARG
+    assert stub.afsk_wav_egress(arr, 0, None, None, None, None) == 0
+    bad = offs.copy(); bad[3] = bad[2]                                         # overlapping streams
+    assert stub.afsk_wav_egress(arr, n, dev.ctypes.data, p64(bad), p32(lens), p32(status)) == _native.E_INVALID_ARG

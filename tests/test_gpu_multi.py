@@ -335,9 +335,9 @@ def test_bench_default_line_at_n1_is_compact_and_complete():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["match_rate"] == 1.0 and d["roundtrip_match_rate"] == 1.0
     subs = d["sub_records"]
-    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_4096",
+    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress", "rates_4096",
             "rates_65536"} <= set(subs)
-    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest"):
+    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest", "f5_wav_egress"):
         assert subs[name]["match_rate"] == 1.0, name
     assert subs["config4"]["ber_equals_cpu"] is True
     full = json.load(open(os.path.join(root, d["full_record"])))

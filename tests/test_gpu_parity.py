@@ -1435,3 +1435,51 @@ def test_grouped_dispatch_plan_api(torch_cuda, entry):
     arrs = batch.demod_host_arrays([h[i * 48000: (i + 1) * 48000] for i in range(n)], b["h_bf"], 14000)
     for f in FIELDS:
         assert np.array_equal(getattr(arrs, f), want[f]), f
+
+
+def test_transmitter_save_batch_writes_the_reference_files(golden, torch_cuda, tmp_path, entry):
+    """Transmitter.save for many payloads (device modulator + afsk_wav_egress): every file equals, byte for byte,
+    what Transmitter.save writes on the host -- which the reference's own digests pin (the 72 frame / wav cases
+    of the fixture: payload samples by SHA-256; the README file by its whole-file digest) -- and decodes back
+    through Receiver.load_batch.  Also a baud rate the device modulator has no geometry for (host fallback) and a
+    batch larger than one staging window."""
+    import hashlib
+    import wave
+    if entry != "uniform":
+        pytest.skip("entry-independent: runs once")
+    afskmodem.LOG_LEVEL = 5
+    by_tx = {}
+    for c in golden["frames"]:
+        by_tx.setdefault((c["baud"], c["training_time"]), []).append(c)
+    for (baud, tt), cases in by_tx.items():
+        t = afskmodem.Transmitter(baud, tt)
+        names = [str(tmp_path / f"g_{baud}_{tt}_{i}.wav") for i in range(len(cases))]
+        t.save_batch([bytes.fromhex(c["payload_hex"]) for c in cases], names)
+        for c, fn in zip(cases, names):
+            with wave.open(fn, "rb") as f:
+                assert (f.getnchannels(), f.getsampwidth(), f.getframerate()) == (1, 2, 48000)
+                raw = f.readframes(f.getnframes())
+            assert len(raw) // 2 == c["n_wav"] and hashlib.sha256(raw).hexdigest() == c["wav_sha256"], (baud, tt, c["payload"])
+            host = tmp_path / "host.wav"
+            t.save(bytes.fromhex(c["payload_hex"]), str(host))
+            assert open(fn, "rb").read() == host.read_bytes(), (baud, tt, c["payload"])
+    readme = tmp_path / "readme.wav"
+    afskmodem.Transmitter(1200).save_batch(["Hello World!"], [str(readme)])
+    assert hashlib.sha256(readme.read_bytes()).hexdigest() == golden["readme_wav_file_sha256"]
+    # 600 x 1 s payloads (57 MB: several staging windows), decoded back
+    t = afskmodem.Transmitter(1200)
+    payloads = [bytes([65 + i % 26]) * 34 for i in range(600)]
+    names = [str(tmp_path / f"b{i:03d}.wav") for i in range(600)]
+    t.save_batch(payloads, names)
+    assert afskmodem.Receiver(1200).load_batch(names) == payloads
+    # 48000 / 8000 = 6 is not a multiple of 4 (mark tone of 4, space tone of 6 samples): the reference still modulates
+    # it, the device modulator has no geometry for it -> host path
+    odd = afskmodem.Transmitter(8000, 0.1)
+    odd.save_batch([b"xy"], [str(tmp_path / "odd.wav")])
+    host = tmp_path / "odd_host.wav"
+    odd.save(b"xy", str(host))
+    assert (tmp_path / "odd.wav").read_bytes() == host.read_bytes()
+    with pytest.raises(ValueError):
+        t.save_batch([b"a", b"b"], [str(tmp_path / "one.wav")])
+    with pytest.raises(FileNotFoundError):
+        t.save_batch([b"a"], [str(tmp_path / "nope" / "x.wav")])
