@@ -945,7 +945,8 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                              "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
                              "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
                              "bound_note": "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
-                                           "the egress also creates, writes (page cache) and closes every file"},
+                                           "the egress also creates / truncates, writes (page cache: one page allocation per 4 KiB) "
+                                           "and closes every file -- that kernel path, not the link, is what limits it"},
                 "files_on": d.split(os.sep)[1] if os.sep in d else d}
     finally:
         shutil.rmtree(d, ignore_errors=True)

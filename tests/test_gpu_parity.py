@@ -1464,7 +1464,7 @@ def test_transmitter_save_batch_writes_the_reference_files(golden, torch_cuda, t
             t.save(bytes.fromhex(c["payload_hex"]), str(host))
             assert open(fn, "rb").read() == host.read_bytes(), (baud, tt, c["payload"])
     readme = tmp_path / "readme.wav"
-    afskmodem.Transmitter(1200).save_batch(["Hello World!"], [str(readme)])
+    afskmodem.Transmitter(1200).save_batch(["Héellóo World!"], [str(readme)])   # the README payload: str -> utf-8 (ref:482-483)
     assert hashlib.sha256(readme.read_bytes()).hexdigest() == golden["readme_wav_file_sha256"]
     # 600 x 1 s payloads (57 MB: several staging windows), decoded back
     t = afskmodem.Transmitter(1200)
