@@ -1672,9 +1672,10 @@ static int wav_egress_impl(const char* const* paths, int32_t n_files, const int1
         }
         if (!failed.load(std::memory_order_relaxed)) {
             const uint32_t total = (uint32_t)stream_len[pc.file] * 2u;
-            // a file inside one window: create + truncate with the open; a file in several pieces: every piece sets the
-            // final size (the pieces of neighbouring windows are written concurrently, in any order)
-            const int fd = open(paths[pc.file], O_WRONLY | O_CREAT | O_CLOEXEC | (pc.whole ? O_TRUNC : 0), 0666);
+            // No O_TRUNC: an existing file is overwritten IN PLACE (its page-cache pages are reused instead of freed and
+            // allocated again) and every piece sets the final size -- the pieces of a file that spans windows are
+            // written concurrently, in any order, and ftruncate to the size a file already has costs nothing.
+            const int fd = open(paths[pc.file], O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
             bool ok = fd >= 0;
             if (ok && !pc.whole) ok = ftruncate(fd, (off_t)(44 + (int64_t)total)) == 0;
             if (ok) {
@@ -1696,6 +1697,7 @@ static int wav_egress_impl(const char* const* paths, int32_t n_files, const int1
                     }
                 }
             }
+            if (ok && pc.whole) ok = ftruncate(fd, (off_t)(44 + (int64_t)total)) == 0;   // (an existing longer file)
             if (fd >= 0 && close(fd) != 0) ok = false;
             if (!ok) out_status[pc.file] = AFSK_WAV_IO;           // that file's problem; the batch goes on
         }

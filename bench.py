@@ -915,11 +915,17 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         names = [os.path.join(d, f"o{i:05d}.wav") for i in range(n_files)]
         torch.cuda.synchronize()
         assert (batch.save_wav_batch(x, offs, lens, names) == 0).all()             # warm: creates the files
-        ts = []
-        for _ in range(reps):
+        ts, ts_over = [], []
+        for _ in range(reps):                                  # NEW files: what a pipeline that produces a corpus does
+            for fn in names:
+                os.unlink(fn)
             t0 = time.perf_counter()
             st = batch.save_wav_batch(x, offs, lens, names)
             ts.append(time.perf_counter() - t0)
+        for _ in range(reps):                                  # existing files of the same size, overwritten in place
+            t0 = time.perf_counter()
+            batch.save_wav_batch(x, offs, lens, names)
+            ts_over.append(time.perf_counter() - t0)
         total_bytes = n_files * STREAM_LEN * 2
         pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
         pin.copy_(x, non_blocking=True)
@@ -940,6 +946,7 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         return {"row": "f5 .wav egress (afsk_wav_egress: device streams -> files)", "files": n_files, "bytes": total_bytes,
                 "reps": reps, "unit": "files/s", "value": round(n_files / med), "all_status_ok": bool((st == 0).all()),
                 "egress_ms": {"median": round(med * 1e3, 3), "best": round(min(ts) * 1e3, 3)},
+                "egress_overwrite_in_place_ms": {"median": round(median(ts_over) * 1e3, 3), "best": round(min(ts_over) * 1e3, 3)},
                 "pinned_hipMemcpy_d2h_ms": round(min(pc) * 1e3, 3), "decoded_match_rate": ok / len(pick),
                 "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2), "unit": "GB/s",
                              "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
