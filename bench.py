@@ -951,7 +951,9 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                 "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2), "unit": "GB/s",
                              "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
                              "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
-                             "bound_note": "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
+                             "frac_overwrite_in_place": round(total_bytes / median(ts_over) / 1e9 / peak, 4),
+                             "bound_note": "NEW files (frac) / existing files overwritten in place (frac_overwrite_in_place); "
+                                           "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
                                            "the egress also creates / truncates, writes (page cache: one page allocation per 4 KiB) "
                                            "and closes every file -- that kernel path, not the link, is what limits it"},
                 "files_on": d.split(os.sep)[1] if os.sep in d else d}
@@ -1109,6 +1111,8 @@ def _sub_summary(name: str, rec: dict) -> dict:
             out["match_rate"] = rec[k]
     if "roundtrip_match_rate" in rec and rec["roundtrip_match_rate"] is not None:
         out["roundtrip"] = rec["roundtrip_match_rate"]
+    if "frac_overwrite_in_place" in (rec.get("roofline") or {}):
+        out["frac_overwrite"] = rec["roofline"]["frac_overwrite_in_place"]
     if "entry" in rec:
         out["entry"] = rec["entry"].replace("afsk_demod_batch", "demod")
     if "ber_curve" in rec:
