@@ -23,6 +23,7 @@ entries = (sys.argv[3] if len(sys.argv) > 3 else "uniform,mixed").split(",")
 rng = np.random.default_rng(seed)
 FIELDS = ("nbytes", "nbits", "clock_idx", "term_frame", "status")
 total_bad = 0
+kept = []        # (pieces, bit_frames) of the first streams of every rate: one batch of ALL rates at the end
 # every rate a Receiver can be built for (36 values of bit_frames)
 for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 750, 800, 500, 480, 400, 375, 250, 240, 200,
              160, 150, 125, 120, 100, 96, 80, 75, 60, 50, 48, 40, 32, 30, 25, 24):
@@ -47,6 +48,7 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
             w = burst[: L - at]
             x[at: at + len(w)] = w
         pieces.append(x)
+    kept.append((pieces[: max(40, n // 10)], bf))
     ln = np.array([len(p) for p in pieces], np.int32)
     gaps = rng.integers(0, 4, len(pieces))
     off = np.concatenate([[1], 1 + np.cumsum(ln[:-1] + gaps[:-1])]).astype(np.int64)
@@ -90,5 +92,28 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
                 print(f"           soft outputs on {m} streams ({entry}): mismatches {sbad} "
                       f"(corrected codewords up to {int(soft['corrected'].max())})", flush=True)
                 total_bad += sbad
+# r4: every rate in ONE batch, rates interleaved -- the per-stream kernel in stream order (bit_frames in device memory)
+# and the grouped dispatch (host-side rates: one launch over the rate-sorted index list), three thresholds
+order = rng.permutation(sum(len(p) for p, _ in kept))
+allp = [(x, bf) for p, bf in kept for x in p]
+pieces = [allp[i][0] for i in order]
+bfa = np.array([allp[i][1] for i in order], np.int32)
+ln = np.array([len(p) for p in pieces], np.int32)
+gaps = rng.integers(0, 4, len(pieces))
+off = np.concatenate([[1], 1 + np.cumsum(ln[:-1] + gaps[:-1])]).astype(np.int64)
+flat = np.zeros(int(off[-1] + ln[-1] + 8), np.int16)
+for o, p in zip(off, pieces):
+    flat[o: o + len(p)] = p
+x = torch.from_numpy(flat).cuda()
+d_off, d_ln, d_bf = torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), torch.from_numpy(bfa).cuda()
+for amp_end in (14000, 0, 22000):
+    want = O.demod_batch(flat, off, ln, bfa, amp_end, out_stride=64, n_threads=os.cpu_count() or 8)
+    for entry, arg in (("mixed", d_bf), ("grouped", bfa)):
+        got = batch.demod_batch(x, d_off, d_ln, arg, amp_end, out_stride=64, entry=entry).cpu()
+        bad = sum(int((getattr(got, f) != want[f]).sum()) for f in FIELDS)
+        nb = np.minimum(want["nbytes"], 64)
+        bad += int(((got.bytes != want["bytes"]) & (np.arange(64)[None, :] < nb[:, None])).any(axis=1).sum())
+        print(f"all {len(kept)} rates in one batch, amp_end {amp_end:5d} {entry:7s}: {len(pieces)} streams, mismatching fields {bad}", flush=True)
+        total_bad += bad
 print("TOTAL MISMATCHES", total_bad)
 sys.exit(1 if total_bad else 0)
