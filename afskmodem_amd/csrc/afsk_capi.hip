@@ -273,13 +273,16 @@ thread_local ThreadStream g_thread_stream2;      // afsk_wav_ingest alternates i
 
 struct CopyJob { char* dst; const char* src; size_t bytes; };
 
-// memcpy a list of pieces, split over a few threads when it is worth it (one core moves
-// ~30 GB/s into pinned memory, the PCIe link takes ~56 GB/s: tools/h2d_probe)
+// memcpy a list of pieces, split over the I/O pool's threads when it is worth it (one core moves ~30 GB/s into
+// pinned memory from a hot source, a few GB/s from cold pages; the PCIe link takes ~56 GB/s: tools/h2d_probe).
+// (r4: the persistent pool instead of std::threads spawned per staging window -- ~100 thread creations per call of
+// the gather entry at 4096 streams.)
+unsigned usable_cpus();
+void pool_run(size_t n, unsigned width, const std::function<void(size_t)>& body);
 void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
     static const unsigned max_threads = [] {
         const char* e = std::getenv("AFSK_COPY_THREADS");
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(8u, std::max(1u, hw / 2));
+        return e ? (unsigned)std::max(1, std::atoi(e)) : std::min(16u, std::max(1u, usable_cpus()));
     }();
     unsigned nt = total >= ((size_t)4 << 20) ? max_threads : 1u;
     if (nt <= 1) {
@@ -301,20 +304,9 @@ void parallel_copy(const std::vector<CopyJob>& jobs, size_t total) {
         }
         parts.push_back(std::move(mine));
     }
-    auto run = [](const std::vector<CopyJob>& v) { for (const CopyJob& j : v) std::memcpy(j.dst, j.src, j.bytes); };
-    // helpers take parts 1.., the caller part 0 and whatever could not get a thread; every
-    // started thread is joined on every path (a joinable std::thread must not be destroyed)
-    std::vector<std::thread> th;
-    size_t spawned = 1;
-    try {
-        th.reserve(parts.size());
-        for (; spawned < parts.size(); spawned++) th.emplace_back(run, std::cref(parts[spawned]));
-    } catch (...) {
-        // no more threads: the rest is copied inline below
-    }
-    if (!parts.empty()) run(parts[0]);
-    for (size_t k = spawned; k < parts.size(); k++) run(parts[k]);
-    for (auto& x : th) x.join();
+    pool_run(parts.size(), (unsigned)parts.size(), [&](size_t k) {
+        for (const CopyJob& j : parts[k]) std::memcpy(j.dst, j.src, j.bytes);
+    });
 }
 
 // A small persistent pool for the file-ingest entries: spawning 15 threads per staging window cost
@@ -462,6 +454,7 @@ template <class F>
 void parallel_for(size_t n, unsigned max_threads, F&& body) {
     io_pool().run(n, max_threads, body);
 }
+void pool_run(size_t n, unsigned width, const std::function<void(size_t)>& body) { io_pool().run(n, width, body); }
 
 // CPUs this process may really use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) where one
 // is set -- hardware_concurrency() reports every core of the host (256 on the GPU boxes, whose containers get
@@ -1028,6 +1021,10 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
     {
         hipError_t e = g_thread_stream.get(&stream);
         if (e != hipSuccess) return hip_fail(e, "hipStreamCreateWithFlags (host-entry stream)");
+    }
+    {
+        cpu_set_t cpus;                                   // the packing threads belong on the device's socket
+        if (device_node_cpus(&cpus)) io_pool().confine_to(cpus);
     }
     ScratchLease lease;
     std::unique_ptr<GroupPlan> plan;      // mixed rates: the host copy of the index list, alive until the final synchronise
