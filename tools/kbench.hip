@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
         int32_t *d_amp, *d_nb, *d_bs, *d_bl, *d_oe;
         CK(hipMalloc(&d_amp, (size_t)n * mb * 4)); CK(hipMalloc(&d_nb, n * 4)); CK(hipMalloc(&d_oe, n * 4));
         CK(hipMalloc(&d_bs, (size_t)n * mbursts * 4)); CK(hipMalloc(&d_bl, (size_t)n * mbursts * 4));
-        afsk::GateArgs g{d_x, d_off, d_len, 18000, 14000, n, mb, mbursts, d_amp, d_nb, d_bs, d_bl, d_oe};
+        afsk::GateArgs g{d_x, d_off, d_len, 18000, 14000, n, L, mb, mbursts, d_amp, d_nb, d_bs, d_bl, d_oe};   // (max_len = L since r4)
         CK(afsk::launch_gate(g, 0)); CK(hipDeviceSynchronize());
         hipEvent_t m0, m1; CK(hipEventCreate(&m0)); CK(hipEventCreate(&m1));
         CK(hipEventRecord(m0, 0));
