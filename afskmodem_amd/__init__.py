@@ -11,7 +11,7 @@ sharding in ``afskmodem_amd.dist``; synthetic workloads in ``afskmodem_amd.synth
 # Log level (0: Debug, 1: Info, 2: Warn, 3: Error, 4: Fatal) -- same global as the reference (:14)
 LOG_LEVEL = 0
 
-from .modem import ECC, Log, Receiver, SoundInput, SoundOutput, Transmitter, Waveforms  # noqa: E402
+from .modem import ECC, Log, Receiver, SoundInput, SoundOutput, Transmitter, Waveforms, load_batch  # noqa: E402
 
 __all__ = ["ECC", "Log", "Receiver", "SoundInput", "SoundOutput", "Transmitter", "Waveforms",
-           "LOG_LEVEL"]
+           "LOG_LEVEL", "load_batch"]

@@ -435,6 +435,36 @@ class Receiver:
 # --------------------------------------------------------------- Transmitter
 
 
+def load_batch(receivers, filenames, string: bool = False):
+    """``Receiver.load`` (ref:420-430) for many files decoded on behalf of SEVERAL Receivers: ``receivers[i]`` decodes
+    ``filenames[i]``.  One parallel .wav ingest for all files (``batch.load_wav_batch``), then one launch per
+    distinct squelch threshold; Receivers of different baud rates share a launch through the rate-grouped dispatch
+    (``afsk_demod_batch_grouped``: the host knows every stream's rate).  Returns the payloads in file order."""
+    import torch
+    from . import batch
+    rxs, names = list(receivers), list(filenames)
+    if len(rxs) != len(names):
+        raise ValueError(f"{len(rxs)} receivers for {len(names)} file names")
+    if not names:
+        return []
+    samples, off, ln, max_len = batch.load_wav_batch(names)
+    lens = ln.cpu().numpy()
+    for rx, n_frames in zip(rxs, lens):
+        rx.check_decodable(int(n_frames))                      # raises what the reference raises for that Receiver
+    bf = np.array([rx.bit_frames for rx in rxs], np.int32)
+    amp = [rx.amp_end_threshold for rx in rxs]
+    out: list = [None] * len(names)
+    stride = batch.out_stride_for(max_len, int(bf.min()))
+    for a in sorted(set(amp)):
+        idx = np.array([i for i, v in enumerate(amp) if v == a], np.int64)
+        d_idx = torch.from_numpy(idx).to(samples.device)
+        res = batch.demod_batch(samples, off[d_idx].contiguous(), ln[d_idx].contiguous(), bf[idx], a, out_stride=stride)
+        torch.cuda.synchronize()
+        for i, data in zip(idx, res.payloads()):
+            out[int(i)] = data.decode("utf-8") if (string and data != b"") else data
+    return out
+
+
 _MAX_STREAM_LEN = (1 << 30) - (1 << 15)      # AFSK_MAX_STREAM_LEN of the C-ABI
 
 

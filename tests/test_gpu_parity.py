@@ -1483,3 +1483,28 @@ def test_transmitter_save_batch_writes_the_reference_files(golden, torch_cuda, t
         t.save_batch([b"a", b"b"], [str(tmp_path / "one.wav")])
     with pytest.raises(FileNotFoundError):
         t.save_batch([b"a"], [str(tmp_path / "nope" / "x.wav")])
+
+
+def test_load_batch_for_several_receivers(torch_cuda, tmp_path, entry):
+    """afskmodem_amd.load_batch: files of five baud rates and two squelch thresholds decoded on behalf of their own
+    Receivers in one ingest + one grouped launch per threshold; every payload equals what that Receiver's own
+    load() returns for the file."""
+    if entry != "grouped":
+        pytest.skip("entry-independent: runs once")
+    afskmodem.LOG_LEVEL = 5
+    rng = np.random.default_rng(77)
+    rx = {b: afskmodem.Receiver(b) for b in (300, 1200, 2400, 375, 96)}
+    rx_hi = afskmodem.Receiver(1200, amp_end_threshold=20000)
+    receivers, names, want = [], [], []
+    for i in range(60):
+        baud = (300, 1200, 2400, 375, 96)[i % 5]
+        data = rng.integers(0, 256, int(rng.integers(0, 6)), dtype=np.uint8).tobytes()
+        fn = str(tmp_path / f"m{i:02d}.wav")
+        afskmodem.Transmitter(baud, 0.1).save(data, fn)
+        r = rx_hi if (baud == 1200 and i % 2) else rx[baud]
+        receivers.append(r); names.append(fn); want.append(data)
+    got = afskmodem.load_batch(receivers, names)
+    assert got == want
+    assert got == [r.load(fn, string=False) for r, fn in zip(receivers, names)]
+    with pytest.raises(ValueError):
+        afskmodem.load_batch(receivers[:3], names[:2])
