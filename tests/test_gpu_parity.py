@@ -1437,6 +1437,7 @@ def test_grouped_dispatch_plan_api(torch_cuda, entry):
         assert np.array_equal(getattr(arrs, f), want[f]), f
 
 
+@pytest.mark.filterwarnings("ignore::pytest.PytestUnraisableExceptionWarning")   # CPython 3.10's Wave_write.__del__ after a failed open
 def test_transmitter_save_batch_writes_the_reference_files(golden, torch_cuda, tmp_path, entry):
     """Transmitter.save for many payloads (device modulator + afsk_wav_egress): every file equals, byte for byte,
     what Transmitter.save writes on the host -- which the reference's own digests pin (the 72 frame / wav cases
