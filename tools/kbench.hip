@@ -46,7 +46,7 @@ static void launch_uflags(const DemodArgs& a, hipStream_t s) {
     const int blocks = (a.n_streams + afsk::kWavesPerBlock - 1) / afsk::kWavesPerBlock;
     DemodArgs b = a;
     b.uniform_bit_frames = KBENCH_BF;
-    if (a.n_streams >= afsk::kHintMinStreamsUniform)
+    if (a.n_streams >= afsk::uniform_big_from(KBENCH_BF))
         hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, true>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
     else
         hipLaunchKernelGGL((afsk::demod_uniform_kernel_t<KBENCH_BF, FLAGS, false>), dim3(blocks), dim3(64 * afsk::kWavesPerBlock), 0, s, b);
