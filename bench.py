@@ -830,6 +830,20 @@ def measure_gate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dic
     return rec
 
 
+def bench_tmpdir(prefix: str, need_bytes: int) -> str:
+    """A scratch directory for the file rows (f3 / f5): on tmpfs (/dev/shm) when there is room -- the boxes' /tmp is an
+    overlay on a disk, where NEW files run into the kernel's dirty-page throttling from the second GB on (measured:
+    14 ms for the first 4096 x 96 KB files of a box, 350+ ms for every later batch) -- else wherever tempfile puts it."""
+    import shutil
+    import tempfile
+    try:
+        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 4 * need_bytes + (1 << 30):
+            return tempfile.mkdtemp(prefix=prefix, dir="/dev/shm")
+    except OSError:
+        pass
+    return tempfile.mkdtemp(prefix=prefix)
+
+
 def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
     """n .wav files (SoundInput.loadFromFile ref:213-217) -> the stream-major
     device layout (afsk_file_sizes + afsk_wav_ingest: one open / header walk / pread / close per file,
@@ -841,7 +855,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
     from afskmodem_amd import batch
     torch = ctx.torch
     afskmodem.LOG_LEVEL = 5
-    d = tempfile.mkdtemp(prefix="afsk_bench_wavs_")
+    d = bench_tmpdir("afsk_bench_wavs_", n_files * 96044)
     try:
         t = afskmodem.Transmitter(1200)
         payloads = [bytes([48 + i]) * 34 for i in range(16)]
@@ -891,7 +905,7 @@ def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                             "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
                                           "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
                                           "(page cache warm: the files were just written)" % reps},
-               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "numa_binding": ctx.numa, "files_on": d.split(os.sep)[1] if os.sep in d else d}
+               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "numa_binding": ctx.numa, "files_on": os.path.dirname(d)}
         del pin, devbuf
         return rec
     finally:
@@ -907,7 +921,7 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
     import wave
     from afskmodem_amd import batch
     torch = ctx.torch
-    d = tempfile.mkdtemp(prefix="afsk_bench_out_")
+    d = bench_tmpdir("afsk_bench_out_", 2 * n_files * 96044)
     try:
         x = torch.randint(-32768, 32767, (n_files * STREAM_LEN,), dtype=torch.int16, device=ctx.dev)
         offs = np.arange(n_files, dtype=np.int64) * STREAM_LEN
@@ -968,7 +982,7 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                                            "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
                                            "the egress also creates / truncates, writes (page cache: one page allocation per 4 KiB) "
                                            "and closes every file -- that kernel path, not the link, is what limits it"},
-                "files_on": d.split(os.sep)[1] if os.sep in d else d}
+                "files_on": os.path.dirname(d)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
