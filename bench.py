@@ -926,8 +926,8 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
         x = torch.randint(-32768, 32767, (n_files * STREAM_LEN,), dtype=torch.int16, device=ctx.dev)
         offs = np.arange(n_files, dtype=np.int64) * STREAM_LEN
         lens = np.full(n_files, STREAM_LEN, np.int32)
-        # a corpus spread over 64 directories (creating a file takes its directory's lock exclusively: 4096 creations
-        # in ONE directory are serialised by the VFS whatever the writer does -- timed too, as `one_directory`)
+        # a corpus spread over 64 directories, and -- `one_directory` -- flat (on a disk-backed file system the two
+        # differ a lot, on tmpfs hardly)
         for k in range(64):
             os.mkdir(os.path.join(d, f"d{k:02d}"))
         names = [os.path.join(d, f"d{i % 64:02d}", f"o{i:05d}.wav") for i in range(n_files)]
@@ -980,8 +980,7 @@ def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
                              "frac_overwrite_in_place": round(total_bytes / median(ts_over) / 1e9 / peak, 4),
                              "bound_note": "NEW files spread over 64 directories (frac) / existing files overwritten in place (frac_overwrite_in_place); "
                                            "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
-                                           "the egress also creates / truncates, writes (page cache: one page allocation per 4 KiB) "
-                                           "and closes every file -- that kernel path, not the link, is what limits it"},
+                                           "for new files the kernel's page allocation (24 pages per file), not the link, is the limit"},
                 "files_on": os.path.dirname(d)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
