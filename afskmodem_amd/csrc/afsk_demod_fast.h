@@ -1012,9 +1012,9 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 
         const int k0 = r * SPR;
         uint64_t B[SPL];
+        int32_t mg[SPL];                                                       // space_diff - mark_diff per slice (soft output)
 #pragma unroll
         for (int piece = 0; piece < SPL; piece++) {
-            const int kk = k0 + 64 * piece;
             if constexpr (BF == 4) {
                 // One sample per quarter.  With the limited samples L0..L3 (biased levels 0 / 0x8000 / 0xFFFF)
                 // mark = (65535 - L0) + L1 + (65535 - L2) + L3 and space = (65535 - L0) + (65535 - L1) + L2 + L3
@@ -1037,8 +1037,9 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
                 for (int d = 0; d < NO; d++)
                     hq[d / (Q / 2)] = __builtin_amdgcn_sad_u16(limit_pair_biased(x[NO * piece + d]), 0xFFFFFFFFu,
                                                               hq[d / (Q / 2)]);
-                mark = 2u * FULL * Q + hq[0] + hq[2] - hq[1] - hq[3];
-                space = 2u * FULL * Q + hq[0] + hq[1] - hq[2] - hq[3];
+                const uint32_t u = 2u * FULL * Q + hq[0] - hq[3], dd = hq[2] - hq[1];   // (modulo 2^32, like the sums)
+                mark = u + dd;
+                space = u - dd;
             } else {
 #pragma unroll
                 for (int d = 0; d < NO; d++) {
@@ -1050,8 +1051,15 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
                 }
             }
             const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
-            if (margins && kk + lane < mlim) margins[kk + lane] = (int32_t)sd - (int32_t)md;
+            mg[piece] = (int32_t)sd - (int32_t)md;
             B[piece] = __ballot(md < sd);                                      // ref:348-351
+        }
+        if constexpr (BF != 4) {
+            if (margins) {                 // soft output, ONE test per round (r4: it sat inside the slice loop)
+#pragma unroll
+                for (int piece = 0; piece < SPL; piece++)
+                    if (k0 + 64 * piece + lane < mlim) margins[k0 + 64 * piece + lane] = mg[piece];
+            }
         }
         if constexpr (BF == 4) {
             if (margins) {                                                     // soft output: the two quotients (ref:346-349)
