@@ -995,7 +995,9 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
     cores = usable_cpus()
     for baud in ALL_RATES:
         sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
-        rec, aux = measure(ctx, sh, steps, warmup, 50.0, 0, 0.0)      # 50 ms pre-roll: every rate starts from settled clocks
+        # 50 ms pre-roll: every rate starts from settled clocks; the figure is the MEDIAN of three K-step regions
+        # (single regions of one rate differ by +-0.03 from run to run)
+        rec, aux = measure(ctx, sh, steps, warmup, 50.0, 0, 3.0 * steps * (0.9 if n_streams >= 32768 else 0.06), 3)
         row = {"bit_frames": 48000 // baud, "payload_bytes": int(sh.plen_h[0]), "entry": rec["entry"],
                "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
                "kernel_ms_median": rec["roofline"]["kernel_ms_median"], "frac": rec["roofline"]["frac"],
