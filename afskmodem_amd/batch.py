@@ -470,6 +470,19 @@ class GateResult:
         off = stream_offset[owner] + self.burst_start[owner, k].to(torch.int64)
         return owner, off.contiguous(), self.burst_len[owner, k].contiguous()
 
+    def burst_slots(self, stream_offset):
+        """The same bursts WITHOUT a host synchronisation (``burst_streams`` compacts with ``nonzero``, which waits for
+        the gate): fixed slots -- slot ``s * max_bursts + k`` = burst k of capture s -- as (offset int64
+        [n * max_bursts], length int32 [n * max_bursts]), length 0 where capture s has fewer than k + 1 bursts (the
+        demodulator answers such a slot with status TOO_SHORT and touches no sample).  gate -> burst_slots ->
+        demod_batch is a chain of asynchronous launches and can be captured into one HIP graph."""
+        torch = _torch()
+        nb = self.burst_start.shape[1]
+        mask = torch.arange(nb, device=self.n_bursts.device)[None, :] < self.n_bursts[:, None]
+        off = torch.where(mask, stream_offset[:, None] + self.burst_start.to(torch.int64), 0)
+        ln = torch.where(mask, self.burst_len, 0)
+        return off.reshape(-1).contiguous(), ln.reshape(-1).contiguous()
+
 
 def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
                amp_start_threshold: int = 18000, amp_end_threshold: int = 14000,

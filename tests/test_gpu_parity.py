@@ -1509,3 +1509,63 @@ def test_load_batch_for_several_receivers(torch_cuda, tmp_path, entry):
     assert got == [r.load(fn, string=False) for r, fn in zip(receivers, names)]
     with pytest.raises(ValueError):
         afskmodem.load_batch(receivers[:3], names[:2])
+
+
+def test_gate_to_demod_chain_without_host_sync_and_as_a_graph(golden, torch_cuda, entry):
+    """f2 -> demod with no host round trip: gate_batch -> GateResult.burst_slots (fixed slots, length 0 where a capture
+    has fewer bursts) -> demod_batch gives, slot by slot, what the compacting route (burst_streams: a nonzero, i.e. a
+    synchronisation) gives burst by burst -- which the reference-recorded listen cases pin -- and the whole chain
+    is captured into ONE HIP graph and replayed on new captures in the same buffer."""
+    from tests.golden_inputs import build_capture
+    if entry != "uniform":
+        pytest.skip("entry-independent: runs once")
+    torch = torch_cuda
+    cases = [c for c in golden["listen_cases"] if c["amp_start"] == 18000]
+    caps = [build_capture(c["recipe"]) for c in cases]
+    samples, off, ln, max_len = batch.upload_streams(caps)
+    mb = 4
+    stride = batch.out_stride_for(max_len, 40)
+
+    def chain(out=None):
+        g = batch.gate_batch(samples, off, ln, max_len, 18000, 14000, mb)
+        s_off, s_len = g.burst_slots(off)
+        return g, batch.demod_batch(samples, s_off, s_len, 40, 14000, out=out, out_stride=None if out is not None else stride)
+
+    g, res = chain()
+    torch.cuda.synchronize()
+    owner, b_off, b_len = g.burst_streams(off)
+    ref = batch.demod_batch(samples, b_off, b_len, 40, 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    nb = g.n_bursts.cpu().numpy()
+    slots, refp = res.cpu(), ref.payloads()
+    k = 0
+    for s_i in range(len(caps)):
+        for j in range(mb):
+            slot = s_i * mb + j
+            if j < nb[s_i]:
+                assert slots.payloads()[slot] == refp[k] and slots.status[slot] == ref.status[k].item(), (s_i, j)
+                k += 1
+            else:
+                assert slots.status[slot] == _native.ST_TOO_SHORT and slots.nbytes[slot] == 0
+    assert k == len(refp) and k > 0
+    for c, s_i in zip(cases, range(len(caps))):                    # and the reference's own bursts
+        for j, b in enumerate(c["bursts"][: mb]):
+            if b["len"] == b["ref_len"]:
+                assert slots.payloads()[s_i * mb + j].hex() == b["bytes_hex"], c["name"]
+    # the chain as one graph, replayed after the captures were swapped for others (same layout)
+    out = batch.alloc_result(len(caps) * mb, stride, "cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            chain(out)
+    out.flat.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert got.payloads() == slots.payloads() and np.array_equal(got.status, slots.status)
+    samples.zero_()                                                  # other data, same graph: silence -> no bursts at all
+    graph.replay()
+    torch.cuda.synchronize()
+    assert (out.cpu().status == _native.ST_TOO_SHORT).all()
