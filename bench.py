@@ -155,7 +155,7 @@ SHARE_GPU0_MAX_RANKS = 4
 def config_block(name: str, n_local: int, world: int, backend: str = "nccl", share_gpu0: bool = False) -> dict:
     """The `config` object of the result line (no GPU needed to build it)."""
     _, bauds, snr, desc = WORKLOADS[name]
-    par = f"stream-sharded x{world}" + (" + RCCL all-gather of decoded records" if world > 1 else "")
+    par = f"stream-sharded x{world}" + (" + RCCL gather of decoded records" if world > 1 else "")
     if backend != "nccl":
         par += " [DIAGNOSTIC: gloo backend" + (", all ranks on one GPU" if share_gpu0 else "") + "]"
     return {"workload": desc, "streams_per_gpu": n_local, "streams_total": n_local * world,
