@@ -1569,3 +1569,37 @@ def test_gate_to_demod_chain_without_host_sync_and_as_a_graph(golden, torch_cuda
     graph.replay()
     torch.cuda.synchronize()
     assert (out.cpu().status == _native.ST_TOO_SHORT).all()
+
+
+def test_full_size_many_rates_one_batch(torch_cuda):
+    """65536 x 1 s with NINE rates interleaved (6000 ... 24 baud: fast, multi-slice, watermark, general-piece and
+    long-symbol geometries; 6.3 GB) in one launch -- per-stream kernel in stream order, uniform kernels per rate
+    (the test's own split) and the grouped dispatch (one launch over the rate-sorted index list, 9 buckets of ~7282
+    streams: hint and warming armed) by the `entry` fixture: every stream decodes to its payload, and the CPU
+    oracle agrees on every 16th stream in every output field."""
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 10 * 2 ** 30:
+        pytest.skip("needs ~7 GB of free HBM")
+    n = 65536
+    rates = (6000, 2400, 1200, 800, 375, 300, 160, 96, 24)
+    b = synth_batch(torch, n, rates, seed=9009)
+    stride = batch.out_stride_for(48000, 8)
+    res = batch.demod_batch(b["samples"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride)
+    torch.cuda.synchronize()
+    got = res.cpu()
+    assert (got.status[b["plen"] > 0] == 0).all() and np.array_equal(got.nbytes, b["plen"])
+    assert (got.clock_idx == 0).all()
+    col = np.arange(b["payload"].shape[1])[None, :]
+    mask = col < b["plen"][:, None]
+    assert np.array_equal(np.where(mask, got.bytes[:, : b["payload"].shape[1]], 0), np.where(mask, b["payload"], 0))
+    sel = np.arange(0, n, 16) + (np.arange(n // 16) % len(rates))       # every 16th stream, rotating through the rates
+    sel = sel[sel < n]
+    h = b["samples"].view(n, -1)[torch.from_numpy(sel).to(b["samples"].device)].cpu().numpy().reshape(-1)
+    want = O.demod_batch(h, np.arange(len(sel), dtype=np.int64) * 48000, np.full(len(sel), 48000, np.int32),
+                         b["h_bf"][sel], 14000, out_stride=stride, n_threads=min(os.cpu_count() or 8, 64))
+    sub = batch.HostDemodResult(got.bytes[sel], *(getattr(got, f)[sel] for f in FIELDS))
+    assert_same(sub, want, "nine rates sample")
+    assert set(b["h_bf"][sel].tolist()) == {48000 // r for r in rates}
+    del b, res
+    torch.cuda.empty_cache()
