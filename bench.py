@@ -1165,6 +1165,8 @@ def compact_line(full: dict, full_path: str | None = None) -> dict:
         line["cpu_baseline"] = cb
     if "gather_ms" in full:
         line["gather_ms"] = _pick(full["gather_ms"], ("median", "max", "bytes_per_rank"))
+    if "headline_again_at_end" in full:
+        line["headline_again_at_end"] = _pick(full["headline_again_at_end"], ("value", "frac"))
     if full.get("sub_records"):
         line["sub_records"] = {k: _sub_summary(k, v) for k, v in full["sub_records"].items()}
     line["full_record"] = full_path
@@ -1305,6 +1307,18 @@ def run_rank(args) -> None:
         if world == 1 and row in next_rows:
             big = n_str >= 32768
             subs[row] = measure_rates(ctx, args.rates_steps or (20 if big else 120), n_str, warmup=3 if big else 10)
+    if world == 1 and subs and not args.workload and args.sub is None:
+        # The chip's power management: a workload measured after seconds of continuous load runs 2-4 % slower than
+        # measured first (tools/order_probe.py).  The headline is measured first; here it is measured AGAIN, last,
+        # in the state every sub-record saw -- reported next to it, never instead of it.
+        shl = Shard(ctx, main_name, n_for(main_name))
+        lrec, _ = measure(ctx, shl, args.steps, args.warmup, 50.0, 0, args.min_region_ms)
+        out["headline_again_at_end"] = {"value": lrec["value"], "ms_per_step": lrec["ms_per_step"],
+                                        "frac": lrec["roofline"]["frac"], "kernel_ms": lrec["roofline"]["kernel_ms"],
+                                        "roundtrip_match_rate": lrec["roundtrip_match_rate"],
+                                        "note": "the headline workload measured again after all sub-records (sustained load)"}
+        del shl
+        torch.cuda.empty_cache()
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
