@@ -1010,8 +1010,11 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
             row["match_rate"], _, _ = oracle_match(sh, aux["res"], aux["got_payloads"], sh.inputs[0],
                                                    min(check_streams, n_streams), cores)
         rows[str(baud)] = row
+        # (no empty_cache(): the next rate's 6.29 GB buffer is the block this one gives back to torch's caching
+        # allocator.  A FRESHLY hipMalloc'ed buffer streams 2-4 % slower for its first seconds -- tools/order_probe.py:
+        # 0.824 right after allocation, 0.841 for the same buffer ten seconds later -- and that is not what
+        # "inputs resident in HBM" means.)
         del sh, aux
-        ctx.torch.cuda.empty_cache()
     fr = [r["frac"] for r in rows.values()]
     slow = sorted(rows, key=lambda b: rows[b]["frac"])[:3]
     doc = {"row": f"{n_streams} x 1 s clean streams at each of the {len(rows)} rates a Receiver can be built for "
@@ -1260,8 +1263,7 @@ def run_rank(args) -> None:
         subs["f1_modulate"] = measure_modulate(ctx, sh, args.next_reps)
     if world == 1 and "f2_gate" in next_rows:
         subs["f2_gate"] = {"captures_%d" % sh.n_local: measure_gate(ctx, sh, args.next_reps)}
-    del sh, aux
-    torch.cuda.empty_cache()
+    del sh, aux            # (back to torch's caching allocator, NOT to the driver: see measure_rates)
 
     # ---------------- sub-records: the other single-GPU configs in the same line
     per_workload = {main_name: out["value"]}
@@ -1296,7 +1298,6 @@ def run_rank(args) -> None:
         per_workload[name] = srec["value"]
         subs[name] = srec
         del shs, saux
-        torch.cuda.empty_cache()
     if world == 1 and "f3_wav_ingest" in next_rows:
         subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
     if world == 1 and "f5_wav_egress" in next_rows:
@@ -1318,7 +1319,6 @@ def run_rank(args) -> None:
                                         "roundtrip_match_rate": lrec["roundtrip_match_rate"],
                                         "note": "the headline workload measured again after all sub-records (sustained load)"}
         del shl
-        torch.cuda.empty_cache()
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
