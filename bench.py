@@ -1309,15 +1309,15 @@ def run_rank(args) -> None:
             big = n_str >= 32768
             subs[row] = measure_rates(ctx, args.rates_steps or (20 if big else 120), n_str, warmup=3 if big else 10)
     if world == 1 and subs and not args.workload and args.sub is None:
-        # The chip's power management: a workload measured after seconds of continuous load runs 2-4 % slower than
-        # measured first (tools/order_probe.py).  The headline is measured first; here it is measured AGAIN, last,
-        # in the state every sub-record saw -- reported next to it, never instead of it.
+        # The headline is necessarily the first allocation of the process, and a given 6.29 GB allocation streams at its
+        # own rate (+-2 %: tools/order_probe.py).  Here the same workload is measured AGAIN, last, in a recycled buffer
+        # like every sub-record -- reported next to the headline, never instead of it.
         shl = Shard(ctx, main_name, n_for(main_name))
         lrec, _ = measure(ctx, shl, args.steps, args.warmup, 50.0, 0, args.min_region_ms)
         out["headline_again_at_end"] = {"value": lrec["value"], "ms_per_step": lrec["ms_per_step"],
                                         "frac": lrec["roofline"]["frac"], "kernel_ms": lrec["roofline"]["kernel_ms"],
                                         "roundtrip_match_rate": lrec["roundtrip_match_rate"],
-                                        "note": "the headline workload measured again after all sub-records (sustained load)"}
+                                        "note": "the headline workload measured again after all sub-records, in a recycled buffer"}
         del shl
     if subs:
         out["sub_records"] = subs
