@@ -10,6 +10,7 @@ only), and the call is one asynchronous kernel launch through the C-ABI
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import math
 import os
 from dataclasses import dataclass
@@ -259,28 +260,32 @@ def _uniform_bit_frames(bit_frames, n: int):
 
 _PLAN_CACHE: "dict[tuple, GroupPlan]" = {}
 _PLAN_CACHE_MAX = 8
+_PLAN_CACHE_LOCK = threading.Lock()
 
 
 def _cached_plan(bit_frames, n: int, dev) -> "GroupPlan":
     """Plans built on behalf of ``demod_batch`` calls that did not bring one: kept per (device, contents)
-    so that decoding the same batch layout again costs one hash of the array, and freed -- after a
-    device synchronise, launches may still be queued -- only when eight newer layouts have displaced them."""
+    so that decoding the same batch layout again costs one hash of the array.  Thread-safe: look-up, insert and
+    eviction happen under one lock, and an evicted plan is only DROPPED from the cache -- it is freed (after a
+    device synchronise: launches may still be queued) when the last reference to it goes, and every DemodResult
+    of a launch that used it holds one.  A captured HIP graph is not such a reference: capture with an explicit
+    ``plan=`` that the caller keeps alive as long as the graph."""
     arr = np.asarray(bit_frames, dtype=np.int32)
     if arr.size not in (1, n):
         raise ValueError(f"bit_frames holds {arr.size} values for {n} streams (1 or {n} expected)")
     arr = np.ascontiguousarray(np.broadcast_to(arr.reshape(-1) if arr.ndim else arr, (n,)))
     key = (str(dev), n, hash(arr.tobytes()))
-    plan = _PLAN_CACHE.get(key)
-    if plan is not None and np.array_equal(plan.bit_frames, arr):
-        _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)          # most recently used last
-        return plan
-    plan = GroupPlan(arr, dev)
-    _PLAN_CACHE[key] = plan
-    while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
-        old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
-        _torch().cuda.synchronize(old.device)
-        old.close()
-    return plan
+    with _PLAN_CACHE_LOCK:
+        plan = _PLAN_CACHE.pop(key, None)
+        if plan is not None and np.array_equal(plan.bit_frames, arr):
+            _PLAN_CACHE[key] = plan                          # most recently used last
+            return plan
+    fresh = GroupPlan(arr, dev)                              # (built outside the lock: an 8 B / stream upload)
+    with _PLAN_CACHE_LOCK:
+        _PLAN_CACHE[key] = fresh
+        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))         # dropped, not closed: GroupPlan.__del__ frees it
+    return fresh
 
 
 class GroupPlan:
@@ -431,6 +436,7 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
                 threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
                 out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
                 out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
+            out._plan_keepalive = plan  # type: ignore[attr-defined]   (the plan's device index list outlives the launch)
             return out
         bf = _as_device_i32(bit_frames, n, dev)
         _order_after_current(stream, dev)

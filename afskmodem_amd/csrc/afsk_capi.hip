@@ -66,15 +66,16 @@ bool device_node_cpus(cpu_set_t* out) {
     if (!enabled) return false;
     int dev = 0, node = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-    // one answer per device and process (two sysfs reads otherwise, on every ingest call)
+    // one answer per device and process (two sysfs reads otherwise, on every ingest call); a process that
+    // drives GPUs on both sockets gets each device's own node
+    constexpr int kMaxCachedDevices = 64;
     static std::mutex cache_mu;
-    static int cached_dev = -1;
-    static bool cached_ok = false;
-    static cpu_set_t cached;
+    static bool known[kMaxCachedDevices], known_ok[kMaxCachedDevices];
+    static cpu_set_t known_cpus[kMaxCachedDevices];
     std::lock_guard<std::mutex> cache_lock(cache_mu);
-    if (cached_dev == dev) { if (cached_ok) *out = cached; return cached_ok; }
-    cached_dev = dev;
-    cached_ok = false;
+    const bool cacheable = dev >= 0 && dev < kMaxCachedDevices;
+    if (cacheable && known[dev]) { if (known_ok[dev]) *out = known_cpus[dev]; return known_ok[dev]; }
+    if (cacheable) { known[dev] = true; known_ok[dev] = false; }
     if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, dev) != hipSuccess || node < 0) {
         (void)hipGetLastError();
         node = -1;
@@ -107,8 +108,8 @@ bool device_node_cpus(cpu_set_t* out) {
     }
     std::fclose(f);
     if (CPU_COUNT(&want) == 0) return false;
-    *out = cached = want;
-    cached_ok = true;
+    *out = want;
+    if (cacheable) { known_cpus[dev] = want; known_ok[dev] = true; }
     return true;
 }
 
@@ -317,9 +318,11 @@ public:
     // from the next job on the pool's threads stay on these CPUs (the device's NUMA node).  Called by the
     // entries that talk to the device anyway -- never by the host-only ones (afsk_wav_probe, afsk_file_sizes
     // make no HIP call, also not to find out where the device lives).
+    // A later call with another mask (the same process ingesting for a GPU on the other socket) moves the
+    // threads: every worker re-applies the affinity when the mask's version differs from the one it applied.
     void confine_to(const cpu_set_t& cpus) {
         std::lock_guard<std::mutex> lk(mu_);
-        if (!confined_) { cpus_ = cpus; confined_ = true; }
+        if (!confined_ || !CPU_EQUAL(&cpus_, &cpus)) { cpus_ = cpus; confined_ = true; cpus_ver_++; }
     }
     ~IoPool() {
         {
@@ -397,15 +400,15 @@ private:
         }
     }
     void worker(uint64_t seen) {
-        bool applied = false;
+        uint64_t applied_ver = 0;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
             cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
             if (quit_) return;
             seen = gen_;
-            if (confined_ && !applied) {
+            if (confined_ && applied_ver != cpus_ver_) {
                 (void)pthread_setaffinity_np(pthread_self(), sizeof cpus_, &cpus_);
-                applied = true;
+                applied_ver = cpus_ver_;
             }
             const std::function<void(size_t)>* fn = fn_;
             const size_t n = n_;
@@ -416,6 +419,7 @@ private:
         }
     }
     cpu_set_t cpus_;
+    uint64_t cpus_ver_ = 0;
     bool confined_ = false;
     std::mutex mu_, job_mu_;
     std::condition_variable cv_, done_cv_;
@@ -478,6 +482,12 @@ unsigned usable_cpus() {
         }
     }
     if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    // one process per GPU: the rank processes of a node (LOCAL_WORLD_SIZE, set by torchrun and by bench.py's
+    // launcher) share these CPUs -- eight ranks with a quota's worth of threads each are throttled together
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int lw = std::atoi(e);
+        if (lw > 1) hw = std::max(1u, hw / (unsigned)lw);
+    }
     return hw;
 }
 
@@ -1425,8 +1435,11 @@ static int wav_ingest_impl(const char* const* paths, int32_t n_files, const int6
                     const uint32_t tag = le16(hdr + 20), channels = le16(hdr + 22), width = (le16(hdr + 34) + 7) / 8;
                     const int64_t framesize = (int64_t)channels * width;
                     const int64_t csize = (int64_t)le32(hdr + 40);
-                    if (tag == 1 && framesize > 0) {
-                        const int64_t form_end = std::min<int64_t>((int64_t)sb.st_size, 8 + (int64_t)le32(hdr + 4));
+                    // (a RIFF size field below 36 puts a chunk header outside the form: the stdlib reader -- and
+                    // wav_probe_fd, which demands pos + 8 <= form_end for both chunk headers -- rejects such a file,
+                    // so it must not be reported OK with 0 data bytes here: the general walk below gives its status)
+                    const int64_t form_end = std::min<int64_t>((int64_t)sb.st_size, 8 + (int64_t)le32(hdr + 4));
+                    if (tag == 1 && framesize > 0 && form_end >= 44) {
                         const int64_t want = (csize / framesize) * framesize;          // getnframes() whole frames
                         const int64_t avail = std::max<int64_t>(0, form_end - 44);
                         doff = 44; dbytes = std::min(want, avail);

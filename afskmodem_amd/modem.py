@@ -75,7 +75,7 @@ class Log:
 def _space_array(baud_rate: int) -> np.ndarray:
     if SAMPLE_RATE % baud_rate != 0:                       # ref:69-70
         raise Exception("Invalid baud rate.")
-    half = int((SAMPLE_RATE / baud_rate) / 2)              # ref:71-76
+    half = max(int((SAMPLE_RATE / baud_rate) / 2), 0)      # ref:71-76 (a negative rate: range(negative), an empty tone)
     return np.concatenate([np.full(half, HI, np.int16), np.full(half, LO, np.int16)])
 
 
@@ -299,7 +299,7 @@ class Receiver:
         frames = np.ascontiguousarray(frames, dtype=np.int16)
         self.check_decodable(len(frames))
         bf = self.__bit_frames
-        if len(frames) < SYNC_WINDOW and (bf % 4 != 0 or 2 * bf >= SYNC_WINDOW):
+        if len(frames) < SYNC_WINDOW and (bf < 4 or bf % 4 != 0 or 2 * bf >= SYNC_WINDOW):
             # A baud the kernels reject only ever reaches the reference's early return
             # (ref:323-325) when the input is too short; mirror that without a launch.
             return b"", 0, -1, -1, _native.ST_TOO_SHORT
@@ -492,7 +492,7 @@ class Transmitter:
         """Transmitter.__getFrames (ref:452-469) as an int16 array."""
         msg = np.unpackbits(np.frombuffer(bytes(data), dtype=np.uint8))   # ref:446-450 MSB first
         ecc = _ecc_encode_array(msg)                                      # ref:455
-        parts = [np.tile(self.__training_cycle, self.__ts_cycles),        # ref:457-458
+        parts = [np.tile(self.__training_cycle, max(self.__ts_cycles, 0)),   # ref:457-458 (range(negative): no cycles)
                  self.__mark_tone, np.tile(self.__space_tone, 3)]          # ref:460-462
         if len(self.__mark_tone) == len(self.__space_tone):
             tones = np.where(ecc[:, None] == 0, self.__space_tone[None, :],
@@ -544,7 +544,8 @@ class Transmitter:
         pay = np.zeros((n, stride), np.uint8)
         for i, p in enumerate(payloads):
             pay[i, : len(p)] = np.frombuffer(p, np.uint8)
-        n_frames = self.__ts_cycles * 2 * bf + 4 * bf + 14 * plen.astype(np.int64) * bf + TAIL_SILENCE   # ref:457-468
+        ts = max(self.__ts_cycles, 0)                                # ref:457: range(negative) runs zero times
+        n_frames = ts * 2 * bf + 4 * bf + 14 * plen.astype(np.int64) * bf + TAIL_SILENCE   # ref:457-468
         lens = (n_frames & ~np.int64(1)).astype(np.int32)            # ref:241: pairs (frames[i], frames[i]) for even i < n - 1
         if int(lens.max()) > _MAX_STREAM_LEN:
             raise ValueError("a payload too long for one stream")
@@ -553,12 +554,13 @@ class Transmitter:
         total = int(offs[-1] + lens[-1])
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
         samples = torch.empty(max(total, 1), dtype=torch.int16, device=dev)
-        batch.modulate_batch(t(pay), t(plen), t(np.full(n, bf, np.int32)), t(np.full(n, self.__ts_cycles, np.int32)),
+        batch.modulate_batch(t(pay), t(plen), t(np.full(n, bf, np.int32)), t(np.full(n, ts, np.int32)),
                              t(offs), t(lens), int(lens.max()), samples, True)
         status = batch.save_wav_batch(samples, offs, lens, names)
-        bad = np.nonzero(status != 0)[0]
-        if bad.size:
-            self.save(payloads[int(bad[0])], names[int(bad[0])])      # raises what the stdlib writer raises for that file
+        for i in np.nonzero(status != 0)[0]:
+            # every file the egress could not write goes through the reference's own per-file path: it is written
+            # after all (a transient open / write failure), or raises what the stdlib writer raises for that file
+            self.save(payloads[int(i)], names[int(i)])
 
     def wav_samples(self, data: str | bytes, total: int | None = None) -> np.ndarray:
         """The int16 samples ``save`` would put in the .wav, optionally zero padded to total."""

@@ -80,6 +80,10 @@ NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress")   # SUR
 RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
 RATES_BIG_ROW = "rates_65536"   # the same at 65536 streams: the steady-state fraction per rate (no launch-shape quantisation)
 RATES_ROWS = {RATES_ROW: 4096, RATES_BIG_ROW: 65536}
+# what the default N = 1 run carries besides configs 2-4: the three SURVEY 8(f) rows and the steady-state per-rate
+# table.  f5_wav_egress (not a SURVEY row) and rates_4096 (launch-shape quantisation, documented and closed) are
+# measured on request: --sub f5_wav_egress,rates_4096
+DEFAULT_RIDERS = ("f1_modulate", "f2_gate", "f3_wav_ingest", RATES_BIG_ROW)
 # 48000 / baud must divide 48000 and be a multiple of 4: 12000 ... 24 baud
 ALL_RATES = tuple(48000 // bf for bf in range(4, 2048, 4) if 48000 % bf == 0)
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
@@ -91,10 +95,12 @@ PAYLOAD_SEED = 2024
 RATE_ORDER = "cycle"            # --rate-order: how --bauds are laid over the streams of a custom workload
 
 
-def usable_cpus() -> int:
-    """CPUs this process may really use: the cgroup CPU quota where one is set (the GPU boxes show all 256 cores
-    of the host to a container that gets the time of 16), else the affinity mask / core count.  The CPU baseline
-    runs on -- and reports as `cores` -- this many threads: threads beyond the quota only get throttled."""
+def usable_cpus(local_world: int | None = None) -> int:
+    """CPUs THIS PROCESS may really use: the cgroup CPU quota where one is set (the GPU boxes show all 256 cores
+    of the host to a container that gets the time of 16), else the affinity mask / core count -- divided by the
+    number of rank processes on this node (LOCAL_WORLD_SIZE: one process per GPU, and eight ranks that each
+    start a quota's worth of threads are throttled for whole 100 ms periods).  The CPU baseline runs on -- and
+    reports as `cores` -- this many threads.  local_world=1 gives the whole box (the launcher's view)."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -112,7 +118,12 @@ def usable_cpus() -> int:
                 n = min(n, max(1, -(-q // p)))
         except (OSError, ValueError):
             pass
-    return n
+    if local_world is None:
+        try:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        except ValueError:
+            local_world = 1
+    return max(1, n // max(1, local_world))
 
 
 def kernel_source_hash() -> str:
@@ -136,7 +147,7 @@ def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
     elif workload or streams:
         names = []
     else:
-        names = ["config2", "config3", "config4"] + list(NEXT_ROWS) + list(RATES_ROWS) if world == 1 else ["config2"]
+        names = ["config2", "config3", "config4"] + list(DEFAULT_RIDERS) if world == 1 else ["config2"]
     riders = NEXT_ROWS + tuple(RATES_ROWS)
     for x in [main] + names:
         if x not in WORKLOADS and x not in riders:
@@ -170,31 +181,366 @@ def free_port() -> int:
     return port
 
 
-def self_launch(n: int, argv: list[str], script: str | None = None) -> int:
-    """Parent of an N > 1 run: never touches the GPU, starts N fresh rank processes, relays
-    rank 0's JSON line; non-zero exit if any rank failed or no line came back.
-    (`script` is this file; tests/test_bench_launch.py passes a stub to exercise the relay.)"""
+def visible_gpus() -> int | None:
+    """GPUs this process could use, counted WITHOUT touching HIP or importing torch: the KFD topology in sysfs
+    (a node with simd_count > 0 is a GPU), narrowed by a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list.
+    None when the topology cannot be read (the launcher then lets the ranks fail loudly themselves)."""
+    import glob
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                   # no KFD driver: no AMD GPU in this machine / container
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    n = 0
+    for p in paths:
+        try:
+            for ln in open(p):
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(",") if x.strip()]))
+    return n
+
+
+# --------------------------------------------------------------------------- heartbeats, deadline, diagnostic line
+#
+# The first real multi-GPU run of this code is the driver's scaling run: the only acceptable outcomes are a line
+# with numbers or a line that says exactly what failed.  Three pieces:
+#   * every rank writes a heartbeat per phase (stderr + one small file per rank in a shared directory);
+#   * bare `python bench.py --gpus N`: the launcher (never touches the GPU, no torch import) watches its rank
+#     children against --deadline-s and their exit codes, terminates them and prints ONE JSON line
+#     (metric, n_gpus, error, phase, per-rank last heartbeat; rank 0's partial result when the headline was
+#     already measured) and exits non-zero;
+#   * under an external torchrun (the driver's own launch) and at N = 1 a watchdog THREAD in every rank does the
+#     same from inside: deadline or SIGTERM (torchrun terminating the survivors of a failed rank) -> the line is
+#     printed by rank 0, or by the lowest surviving rank, then os._exit.  It works while the main thread hangs in
+#     a collective: the C-level signal handler only writes to a wake-up pipe that the thread reads.
+HB_MAX_AGE_S = 1800.0        # heartbeat files older than this belong to an earlier run on the same port
+EXIT_RANK_FAILED, EXIT_DEADLINE, EXIT_NO_LINE = 3, 4, 1
+
+
+def hb_dir_for_env(env=None) -> str:
+    """The heartbeat directory of this job: AFSK_BENCH_HB_DIR (set by the launcher), else one derived from the
+    rendezvous port, so that the ranks of an external torchrun agree on it without talking to each other."""
+    import tempfile
+    env = os.environ if env is None else env
+    d = env.get("AFSK_BENCH_HB_DIR")
+    if not d:
+        # the ranks of one torchrun share their parent (the agent); consecutive jobs on one port do not
+        job = os.getppid() if "RANK" in env else os.getpid()
+        d = os.path.join(tempfile.gettempdir(), "afsk_bench_hb_%s_%s_%s" % (env.get("MASTER_PORT", "solo"), os.getuid(), job))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+class Heartbeat:
+    """Per-rank phase marks: a line on stderr and rank<r>.json in the job's heartbeat directory (atomic rename)."""
+
+    def __init__(self, rank: int, world: int, hb_dir: str | None = None):
+        self.rank, self.world = rank, world
+        self.dir = hb_dir or hb_dir_for_env()
+        self.t_start = time.time()
+        self.phase = "start"
+        # stderr stays small (the driver keeps one ~8 KB tail of stdout + stderr, and the result line must survive in
+        # it): rank 0 of an N > 1 run narrates its phases, every other rank -- and an N = 1 run -- only writes the file
+        self.quiet = not ((rank == 0 and world > 1) or os.environ.get("AFSK_BENCH_VERBOSE") == "1")
+        self.beat("process up")
+
+    def beat(self, phase: str) -> None:
+        self.phase = phase
+        now = time.time()
+        doc = {"rank": self.rank, "pid": os.getpid(), "phase": phase, "t": now, "t_start": self.t_start,
+               "since_start_s": round(now - self.t_start, 2)}
+        try:
+            tmp = os.path.join(self.dir, f".rank{self.rank}.{os.getpid()}.tmp")
+            with open(tmp, "w") as f:
+                json.dump(doc, f)
+            os.replace(tmp, os.path.join(self.dir, f"rank{self.rank}.json"))
+        except OSError:
+            pass
+        if not self.quiet:
+            sys.stderr.write(f"bench.py[rank {self.rank}/{self.world}] +{now - self.t_start:7.2f}s  {phase}\n")
+            sys.stderr.flush()
+        # fault injection for the rehearsals of the failure paths (tests only): AFSK_BENCH_FAULT=<rank>:<die|hang>:<phase prefix>
+        fault = os.environ.get("AFSK_BENCH_FAULT")
+        if fault:
+            r_, _, rest = fault.partition(":")
+            kind, _, prefix = rest.partition(":")
+            if r_ == str(self.rank) and prefix and phase.startswith(prefix):
+                if kind == "die":
+                    os._exit(7)
+                if kind == "hang":
+                    time.sleep(3600)
+
+    def write_partial(self, line: dict) -> None:
+        """Rank 0: the result line as it stands (headline measured, riders possibly missing) -- what the
+        launcher or a watchdog prints, with the error attached, if the run dies later."""
+        try:
+            tmp = os.path.join(self.dir, f".partial.{os.getpid()}.tmp")
+            with open(tmp, "w") as f:
+                json.dump(line, f)
+            os.replace(tmp, os.path.join(self.dir, "partial.json"))
+        except OSError:
+            pass
+
+
+def read_heartbeats(hb_dir: str, world: int) -> dict:
+    """{rank: {phase, age_s, since_start_s, alive}} of every rank that has written one (recent files only)."""
+    out = {}
+    now = time.time()
+    for r in range(world):
+        try:
+            doc = json.load(open(os.path.join(hb_dir, f"rank{r}.json")))
+        except (OSError, ValueError):
+            out[str(r)] = {"phase": "no heartbeat", "age_s": None}
+            continue
+        if now - doc.get("t", 0) > HB_MAX_AGE_S:
+            out[str(r)] = {"phase": "no heartbeat (stale file)", "age_s": None}
+            continue
+        alive = None
+        try:
+            os.kill(int(doc["pid"]), 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        except (OSError, ValueError, KeyError):
+            pass
+        out[str(r)] = {"phase": str(doc.get("phase"))[:120], "age_s": round(now - doc.get("t", now), 1),
+                       "since_start_s": doc.get("since_start_s"), "alive": alive}
+    return out
+
+
+def read_partial(hb_dir: str) -> dict | None:
+    try:
+        p = os.path.join(hb_dir, "partial.json")
+        if time.time() - os.path.getmtime(p) > HB_MAX_AGE_S:
+            return None
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return None
+
+
+def failure_line(n_gpus: int, steps, warmup, error: str, phase: str, heartbeats: dict, partial: dict | None = None,
+                 printed_by: str = "launcher") -> dict:
+    """The ONE line of a run that did not finish: the contract's keys (value null unless the headline had
+    been measured: then rank 0's partial line, complete as far as it got) + error, phase, per-rank heartbeats."""
+    if partial and partial.get("value") is not None:
+        line = dict(partial)
+        line["incomplete"] = True
+    else:
+        line = {"metric": METRIC, "value": None, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16",
+                "data": "synthetic", "config": {"workload": WORKLOADS[HEADLINE][3]}, "roofline": None}
+    line["error"] = error[:600]
+    line["phase"] = phase[:160]
+    line["heartbeats"] = heartbeats
+    line["printed_by"] = printed_by
+    text = json.dumps(line)
+    if len(text) >= LINE_CAP:                       # never over the cap: drop the bulky summaries first
+        for victim in ("sub_records", "per_workload_value", "cpu_baseline"):
+            if victim in line and len(json.dumps(line)) >= LINE_CAP:
+                line[victim] = "see full_record"
+    return line
+
+
+def _kill_group(p, sig) -> None:
+    try:
+        os.killpg(p.pid, sig)
+    except (ProcessLookupError, PermissionError, OSError):
+        try:
+            p.send_signal(sig)
+        except (ProcessLookupError, OSError):
+            pass
+
+
+def self_launch(n: int, argv: list[str], script: str | None = None, deadline_s: float = 420.0,
+                grace_s: float = 5.0, steps=None, warmup=None) -> int:
+    """Parent of an N > 1 run: never touches the GPU (and never imports torch), starts N fresh rank processes
+    itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, each in its own session), relays
+    rank 0's JSON line.  If a rank exits non-zero or the deadline passes it terminates every rank (SIGTERM, then
+    SIGKILL after grace_s), prints ONE diagnostic JSON line (failure_line) and returns non-zero.
+    (`script` is this file; tests/test_bench_launch.py passes stubs to exercise relay, failure and deadline.)"""
+    import signal
+    import tempfile
+    import threading
+    hb_dir = tempfile.mkdtemp(prefix="afsk_bench_hb_")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this pool
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           script or os.path.abspath(__file__)] + argv
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    assert p.stdout is not None
-    for ln in p.stdout:
-        if ln.startswith('{"metric"'):
-            line = ln.strip()
-        else:
-            sys.stderr.write(ln)
-    rc = p.wait()
-    if line is not None:
-        print(line, flush=True)
-    if rc == 0 and line is None:
+    # host threads: the box's usable CPUs are shared by the N ranks (OpenMP, the I/O pool of libafsk_amd.so and
+    # the CPU-oracle legs all size themselves from these)
+    share = max(1, usable_cpus(local_world=1) // n)
+    env["OMP_NUM_THREADS"] = str(min(int(env.get("OMP_NUM_THREADS", share)), share))
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(free_port()), "AFSK_BENCH_HB_DIR": hb_dir, "AFSK_BENCH_LAUNCHER": "1",
+                "AFSK_BENCH_DEADLINE_S": str(deadline_s)})
+    cmd = [sys.executable, "-u", script or os.path.abspath(__file__)] + argv
+    procs, readers = [], []
+    lines: list = []
+
+    def pump(r: int, stream) -> None:
+        for ln in stream:
+            if r == 0 and ln.startswith('{"metric"'):
+                lines.append(ln.strip())
+            else:
+                sys.stderr.write(ln)
+
+    t0 = time.monotonic()
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        th = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
+        th.start()
+        procs.append(p)
+        readers.append(th)
+    failure = None            # (exit code of the launcher, error text)
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failure = (EXIT_RANK_FAILED, "rank(s) exited non-zero: " + ", ".join(
+                f"rank {r} -> " + (f"signal {-c}" if c < 0 else f"exit code {c}") for r, c in bad))
+            break
+        if all(c == 0 for c in codes):
+            break
+        if deadline_s > 0 and time.monotonic() - t0 > deadline_s:
+            failure = (EXIT_DEADLINE, f"deadline of {deadline_s:g} s passed with rank(s) "
+                       + ", ".join(str(r) for r, c in enumerate(codes) if c is None) + " still running")
+            break
+        time.sleep(0.05)
+    hbs = read_heartbeats(hb_dir, n) if failure else None
+    if failure:
+        for p in procs:
+            if p.poll() is None:
+                _kill_group(p, signal.SIGTERM)
+        t_end = time.monotonic() + grace_s
+        while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                _kill_group(p, signal.SIGKILL)
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
+    for th in readers:
+        th.join(timeout=2.0)
+    rc = 0
+    if failure:
+        rc, err = failure
+        partial = json.loads(lines[-1]) if lines else read_partial(hb_dir)
+        print(json.dumps(failure_line(n, steps, warmup, err, (hbs.get("0") or {}).get("phase", "?"), hbs, partial)),
+              flush=True)
+    elif lines:
+        print(lines[-1], flush=True)
+    else:
+        rc = EXIT_NO_LINE
         sys.stderr.write("bench.py: the ranks exited without a result line\n")
-        rc = 1
+        print(json.dumps(failure_line(n, steps, warmup, "every rank exited with code 0 but rank 0 printed no result line",
+                                      "?", read_heartbeats(hb_dir, n), read_partial(hb_dir))), flush=True)
+    import shutil
+    shutil.rmtree(hb_dir, ignore_errors=True)
     return rc
+
+
+class Watchdog:
+    """In-rank guard (external torchrun, N = 1): deadline and SIGTERM handling on a thread of its own.
+    The main thread may hang inside a HIP or RCCL call for ever: Python-level signal handlers would never run,
+    but signal.set_wakeup_fd() makes the C-level handler write the signal number into a pipe this thread reads.
+    On SIGTERM / deadline: the printer (rank 0; or, if rank 0's process is gone, the lowest rank that wins the
+    claim file) prints failure_line -- rank 0's partial result when the headline had been measured -- and every
+    rank ends with os._exit.  Under bench.py's own launcher the launcher prints, the ranks only exit."""
+
+    def __init__(self, hb: Heartbeat, args, deadline_s: float):
+        import signal
+        import threading
+        self.hb, self.args = hb, args
+        self.deadline = time.monotonic() + deadline_s if deadline_s > 0 else None
+        self.deadline_s = deadline_s
+        self.done = threading.Event()          # the result line is out: stand down
+        self.under_launcher = os.environ.get("AFSK_BENCH_LAUNCHER") == "1"
+        self.main_thread_id = threading.main_thread().ident
+        self.rfd, self.wfd = os.pipe()
+        os.set_blocking(self.wfd, False)
+        os.set_blocking(self.rfd, False)
+        signal.set_wakeup_fd(self.wfd, warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *_: None)     # keep the process alive: the thread decides
+        self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self.thread.start()
+
+    def stand_down(self) -> None:
+        self.done.set()
+
+    def _main_stack(self) -> str:
+        import traceback
+        fr = sys._current_frames().get(self.main_thread_id)
+        if fr is None:
+            return "?"
+        st = traceback.extract_stack(fr)[-4:]
+        return " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in reversed(st))
+
+    def _run(self) -> None:
+        import select
+        import signal
+        while not self.done.is_set():
+            try:
+                ready, _, _ = select.select([self.rfd], [], [], 0.25)
+            except OSError:
+                return
+            if self.done.is_set():
+                return
+            if ready:
+                try:
+                    data = os.read(self.rfd, 64)
+                except OSError:
+                    data = b""
+                if int(signal.SIGTERM) in data:
+                    self._fire(EXIT_RANK_FAILED, "SIGTERM received (another rank failed or the launcher gave up)")
+                    return
+            if self.deadline is not None and time.monotonic() > self.deadline:
+                self._fire(EXIT_DEADLINE, f"deadline of {self.deadline_s:g} s passed")
+                return
+
+    def _fire(self, rc: int, why: str) -> None:
+        hb = self.hb
+        where = f"{hb.phase} [main thread at {self._main_stack()}]"
+        hb.quiet = True
+        last_phase = hb.phase
+        hb.beat(f"aborted in '{last_phase}': {why}")
+        sys.stderr.write(f"bench.py[rank {hb.rank}] {why}; was in: {where}\n")
+        sys.stderr.flush()
+        if not self.under_launcher:
+            self._maybe_print(rc, why, where)
+        try:
+            sys.stdout.flush()
+        except Exception:  # noqa: BLE001
+            pass
+        os._exit(rc)
+
+    def _maybe_print(self, rc: int, why: str, where: str) -> None:
+        hb = self.hb
+        claim = os.path.join(hb.dir, "line_printed.claim")
+        if hb.rank != 0:
+            # rank 0 prints if it can; the others step in, lowest rank first, only if nobody has
+            time.sleep(min(6.0, 1.5 * hb.rank))
+        try:
+            if os.path.exists(claim) and time.time() - os.path.getmtime(claim) > HB_MAX_AGE_S:
+                os.unlink(claim)                                   # left over from an earlier job on this port
+            fd = os.open(claim, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+            os.write(fd, str(hb.rank).encode())
+            os.close(fd)
+        except OSError:
+            return                                                 # somebody else has printed the line
+        hbs = read_heartbeats(hb.dir, hb.world)
+        phase0 = (hbs.get("0") or {}).get("phase", "?")
+        line = failure_line(hb.world, self.args.steps, self.args.warmup, f"rank {hb.rank}: {why}",
+                            where if hb.rank == 0 else phase0, hbs, read_partial(hb.dir), f"rank {hb.rank}")
+        print(json.dumps(line), flush=True)
 
 
 # --------------------------------------------------------------------------- one rank
@@ -203,39 +549,57 @@ def self_launch(n: int, argv: list[str], script: str | None = None) -> int:
 class Ctx:
     """Per-process state: device, streams, process group."""
 
-    def __init__(self, args):
-        import torch
-        import torch.distributed as dist
-        from afskmodem_amd import _native
-        self.torch, self.dist, self.args = torch, dist, args
+    def __init__(self, args, hb: "Heartbeat | None" = None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.hb = hb or Heartbeat(self.rank, self.world)
+        self.hb.beat("importing torch")
+        import datetime
+        import torch
+        import torch.distributed as dist
+        from afskmodem_amd import _native
+        self.torch, self.dist, self.args = torch, dist, args
+        self.hb.beat("checking for a HIP device")
         _native.require_device()          # no GPU -> loud failure, never a CPU fallback
         # --share-gpu0 (diagnostic, with --dist-backend gloo): every rank uses device 0, so the whole
         # N > 1 flow (launcher, ranks, gather, per-rank checks) can be exercised on a 1-GPU box;
         # RCCL itself refuses two ranks on one device
         dev_index = 0 if args.share_gpu0 else self.local_rank
+        if not args.share_gpu0 and dev_index >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {self.rank} wants device {dev_index} but only "
+                             f"{torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
         # one process per GPU, on the socket its GPU hangs off (host side of the PCIe traffic: f3, host entries)
         from afskmodem_amd import dist as adist
         self.numa = adist.bind_to_device_numa_node(self.dev)
+        self.hb.beat(f"device set: cuda:{dev_index} ({torch.cuda.get_device_name(dev_index)}), numa {self.numa}")
         self.use_dist = self.world > 1 or args.force_gather
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:
                 os.environ["MASTER_PORT"] = str(free_port())   # single-rank --force-gather only
+            # a rank that never arrives must not hold the others for torch's default 10 / 30 minutes
+            tmo = datetime.timedelta(seconds=args.pg_timeout_s)
             if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=tmo)
             else:
-                dist.init_process_group(args.dist_backend, rank=self.rank, world_size=self.world)
+                dist.init_process_group(args.dist_backend, rank=self.rank, world_size=self.world, timeout=tmo)
+            self.hb.beat(f"pg up: backend {args.dist_backend}, world {self.world}, timeout {args.pg_timeout_s:g} s")
         self.backend = args.dist_backend
         self.lib = _native.lib()
         self.cur = torch.cuda.current_stream()
         self.comm = torch.cuda.Stream(device=self.dev) if self.use_dist else None
+        if self.use_dist:
+            # the first collective builds the communicator (RCCL: topology detection, xGMI rings): do it here,
+            # under its own heartbeat, not inside the first timed fence
+            one = torch.ones(1, dtype=torch.int32, device=self.dev)
+            self.all_reduce(one)
+            torch.cuda.synchronize()
+            self.hb.beat(f"first collective done: {int(one.item())} ranks answered")
 
     def t(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -370,15 +734,17 @@ def median(v):
 
 
 def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gather_every: int = 0,
-            min_region_ms: float = 50.0, max_regions: int = 64):
+            min_region_ms: float = 50.0, max_regions: int = 64, with_gather: bool = True):
     """Pre-roll, W warm-up steps, then timed regions of EXACTLY K steps between two fences each: one
     region, or -- when a region is shorter than min_region_ms -- as many as add up to it; the reported
     region is the median one.  Every step writes its own output slot; with a process group the slots
-    of G consecutive steps are all-gathered by ONE collective on a side stream while the next group
-    runs."""
+    of G consecutive steps are gathered by ONE collective on a side stream while the next group
+    runs.  with_gather=False: the same regions (fences and the max over ranks included) without the
+    exchange of the decoded records -- `value_no_gather`, so that weak-scaling efficiency and the cost of
+    the gather separate."""
     from afskmodem_amd import _native, batch
     torch, dist = ctx.torch, ctx.dist
-    cur, comm = ctx.cur, ctx.comm
+    cur, comm = ctx.cur, (ctx.comm if with_gather else None)
     n_local, stride, flat_sz = sh.n_local, sh.stride, sh.flat_sz
     world, rank = ctx.world, ctx.rank
 
@@ -720,314 +1086,8 @@ def attach_traffic(rec: dict, name: str, n_local: int, src_hash: str) -> None:
                                 f"{tj.get('kernel_source_hash')}, this build is {src_hash}")
         return
     rf["traffic"] = ent.get("hbm_bytes_per_launch")
-    rf["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel source "
-                            f"({src_hash}) on another run: {ent.get('source')}; not measured in this run")
-
-
-def event_timed(torch, stream, launch, reps: int, warm: int = 3):
-    """reps launches on `stream`, one HIP-event interval per launch -> (avg_ms, median_ms, all)."""
-    for _ in range(warm):
-        launch()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    marks[0].record(stream)
-    for k in range(reps):
-        launch()
-        marks[k + 1].record(stream)
-    torch.cuda.synchronize()
-    ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(reps)]
-    return sum(ms) / len(ms), median(ms), ms
-
-
-def roofline_obj(alg_bytes: int, avg_ms: float, med_ms: float, bound: str = "hbm", peak: float = HBM_PEAK_GBS) -> dict:
-    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-    return {"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "GB/s",
-            "frac": round(ach / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes),
-            "kernel_ms": round(avg_ms, 5), "kernel_ms_median": round(med_ms, 5),
-            "frac_at_median": round(alg_bytes / (med_ms * 1e-3) / 1e9 / peak, 4)}
-
-
-def measure_modulate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dict:
-    """the on-device modulator (Transmitter.__getFrames ref:452-469 + ECC.encode
-    ref:166-175 + the .wav writer quirk ref:239-244) re-writing the shard's whole input buffer.
-    Write-bound: 2 B per sample out (+ the payload bytes and 24 B of per-stream metadata in)."""
-    from afskmodem_amd import _native
-    torch = ctx.torch
-    x = sh.inputs[0]
-    sptr = C.c_void_p(ctx.cur.cuda_stream)
-    quirk = 0 if 12000 in sh.bauds else 1
-    args_ = (sh._payload_d.data_ptr(), int(sh._payload_d.shape[1]), sh._plen_d.data_ptr(), sh.bf.data_ptr(),
-             sh._ts_d.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), STREAM_LEN, sh.n_local, quirk, x.data_ptr(), sptr)
-
-    def launch():
-        rc = ctx.lib.afsk_modulate_batch(*args_)
-        if rc != 0:
-            _native.check(rc)
-
-    x.zero_()
-    avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
-    alg = 2 * sh.n_local * STREAM_LEN + int(sh.plen_h.sum()) + 24 * sh.n_local
-    rec = {"row": "f1 on-device modulator (afsk_modulate_batch)", "streams": sh.n_local, "stream_len": STREAM_LEN,
-           "bauds": list(sh.bauds), "launches": reps, "unit": "Msamples/s",
-           "value": round(sh.n_local * STREAM_LEN / (avg * 1e-3) / 1e6, 1),
-           "roofline": roofline_obj(alg, avg, med)}
-    rec["roofline"]["bound_note"] = "HBM WRITE bound: 2 B per sample stored once"
-    if not ctx.args.no_cpu_baseline:
-        from oracle import afsk_oracle as O   # checker only, after the timed launches
-        ns = min(check_streams, sh.n_local)
-        got = x[: ns * STREAM_LEN].cpu().numpy().reshape(ns, STREAM_LEN)
-        want = O.modulate_batch(sh.payload_h[:ns], sh.plen_h[:ns], sh.bf_h[:ns],
-                                np.asarray([int(t) for t in sh._ts_d[:ns].cpu().numpy()], np.int32),
-                                np.arange(ns, dtype=np.int64) * STREAM_LEN, np.full(ns, STREAM_LEN, np.int32),
-                                ns * STREAM_LEN, bool(quirk)).reshape(ns, STREAM_LEN)
-        rec["oracle_match_rate"] = float((got == want).all(axis=1).mean())
-        rec["oracle_sample_streams"] = ns
-    return rec
-
-
-def measure_gate(ctx: Ctx, sh: Shard, reps: int, check_streams: int = 64) -> dict:
-    """live-gate replay (Receiver.__listen ref:299-319: 2048-frame block amplitudes,
-    start > 18000, stop < 14000) over the shard's streams as captures.  Read-bound: 2 B per sample of
-    every whole 2048-frame block in (+ 4 B per block and 12 B per capture out)."""
-    from afskmodem_amd import _native
-    torch = ctx.torch
-    n = sh.n_local
-    max_blocks, max_bursts = STREAM_LEN // 2048, 4
-    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=ctx.dev)  # noqa: E731
-    amp, nb, bs, bl, oe = i32(n, max_blocks), i32(n), i32(n, max_bursts), i32(n, max_bursts), i32(n)
-    sptr = C.c_void_p(ctx.cur.cuda_stream)
-    nin = len(sh.inputs)
-    calls = [(x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), STREAM_LEN, 18000, 14000, n, max_bursts,
-              amp.data_ptr(), nb.data_ptr(), bs.data_ptr(), bl.data_ptr(), oe.data_ptr(), sptr) for x in sh.inputs]
-    k = [0]
-
-    def launch():
-        rc = ctx.lib.afsk_gate_batch(*calls[k[0] % nin])
-        k[0] += 1
-        if rc != 0:
-            _native.check(rc)
-
-    avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
-    alg = 2 * n * max_blocks * 2048 + 4 * n * max_blocks + 12 * n
-    rec = {"row": "f2 live-gate replay (afsk_gate_batch: block amplitudes + burst scan)", "captures": n,
-           "capture_len": STREAM_LEN, "launches": reps, "input_buffers_rotated": nin, "unit": "Msamples/s",
-           "value": round(n * STREAM_LEN / (avg * 1e-3) / 1e6, 1),
-           "bursts_found": int(nb.sum().item()),
-           "roofline": roofline_obj(alg, avg, med)}
-    if not ctx.args.no_cpu_baseline:
-        from oracle import afsk_oracle as O   # checker only
-        ns = min(check_streams, n)
-        h = sh.inputs[(k[0] - 1) % nin][: ns * STREAM_LEN].cpu().numpy().reshape(ns, STREAM_LEN)
-        g_nb, g_bs, g_bl, g_oe = (t[:ns].cpu().numpy() for t in (nb, bs, bl, oe))
-        ok = 0
-        for i in range(ns):
-            bursts, open_end = O.gate_stream(h[i], 18000, 14000, max_bursts)
-            k_ = int(g_nb[i])
-            ok += bool(len(bursts) == k_ and open_end == int(g_oe[i])
-                       and bursts == [(int(g_bs[i, j]), int(g_bl[i, j])) for j in range(k_)])
-        rec["oracle_match_rate"] = ok / ns
-        rec["oracle_sample_streams"] = ns
-    return rec
-
-
-def bench_tmpdir(prefix: str, need_bytes: int) -> str:
-    """A scratch directory for the file rows (f3 / f5): on tmpfs (/dev/shm) when there is room -- the boxes' /tmp is an
-    overlay on a disk, where NEW files run into the kernel's dirty-page throttling from the second GB on (measured:
-    14 ms for the first 4096 x 96 KB files of a box, 350+ ms for every later batch) -- else wherever tempfile puts it."""
-    import shutil
-    import tempfile
-    try:
-        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 4 * need_bytes + (1 << 30):
-            return tempfile.mkdtemp(prefix=prefix, dir="/dev/shm")
-    except OSError:
-        pass
-    return tempfile.mkdtemp(prefix=prefix)
-
-
-def measure_wav_ingest(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
-    """n .wav files (SoundInput.loadFromFile ref:213-217) -> the stream-major
-    device layout (afsk_file_sizes + afsk_wav_ingest: one open / header walk / pread / close per file,
-    pipelined against the H2D copies), then decoded by Receiver.load_batch.
-    PCIe-bound: measured against ONE pinned hipMemcpy of the same byte count on this box."""
-    import shutil
-    import tempfile
-    import afskmodem_amd as afskmodem
-    from afskmodem_amd import batch
-    torch = ctx.torch
-    afskmodem.LOG_LEVEL = 5
-    d = bench_tmpdir("afsk_bench_wavs_", n_files * 96044)
-    try:
-        t = afskmodem.Transmitter(1200)
-        payloads = [bytes([48 + i]) * 34 for i in range(16)]
-        for i, pl in enumerate(payloads):
-            t.save(pl, os.path.join(d, f"seed{i}.wav"))
-        names = []
-        for i in range(n_files):
-            fn = os.path.join(d, f"f{i:05d}.wav")
-            shutil.copyfile(os.path.join(d, f"seed{i % 16}.wav"), fn)
-            names.append(fn)
-        total_bytes = sum(os.path.getsize(f) for f in names)
-
-        def timed(fn_):
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                fn_()
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            return ts
-
-        batch.load_wav_batch(names, ctx.dev)                       # warm, untimed: I/O pool, pinned buffers, torch's
-        torch.cuda.synchronize()                                   # allocator (a first 393 MB block is a hipMalloc)
-        ing = timed(lambda: batch.load_wav_batch(names, ctx.dev))
-        pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
-        devbuf = torch.empty(total_bytes // 2, dtype=torch.int16, device=ctx.dev)
-        devbuf.copy_(pin, non_blocking=True)
-        torch.cuda.synchronize()
-        pc = timed(lambda: devbuf.copy_(pin, non_blocking=True))
-        rx = afskmodem.Receiver(1200)
-        e2e = timed(lambda: rx.load_batch(names, string=False))
-        decoded = rx.load_batch(names, string=False)
-        ok = sum(decoded[i] == payloads[i % 16] for i in range(n_files))
-        avg, med = sum(ing) / len(ing), median(ing)
-        peak = total_bytes / min(pc) / 1e9
-        rec = {"row": "f3 .wav ingest (afsk_file_sizes + afsk_wav_ingest: one pass per file)", "files": n_files,
-               "bytes": total_bytes, "reps": reps, "unit": "files/s", "value": round(n_files / med),
-               "ingest_ms": {"median": round(med * 1e3, 3), "best": round(min(ing) * 1e3, 3)},
-               "pinned_hipMemcpy_ms": round(min(pc) * 1e3, 3),
-               "load_batch_end_to_end_ms": {"median": round(median(e2e) * 1e3, 3), "best": round(min(e2e) * 1e3, 3)},
-               "decoded_match_rate": ok / n_files,
-               # host-side wall times (Python + syscalls + H2D): the MEDIAN call is the figure, the mean rides along
-               "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2),
-                            "unit": "GB/s", "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
-                            "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
-                            "kernel_ms_mean": round(avg * 1e3, 3),
-                            "bound_note": "host -> device link: peak = one pinned hipMemcpy of the same bytes measured in this "
-                                          "run (best of %d); the ingest also stats, opens, walks, preads and closes every file "
-                                          "(page cache warm: the files were just written)" % reps},
-               "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "numa_binding": ctx.numa, "files_on": os.path.dirname(d)}
-        del pin, devbuf
-        return rec
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-
-
-def measure_wav_egress(ctx: Ctx, n_files: int = 4096, reps: int = 5) -> dict:
-    """The mirror of f3 (r4): n streams of 1 s in device memory -> n canonical .wav files (afsk_wav_egress: D2H
-    through the pinned ring, one open / pwritev / close per file; what Transmitter.save_batch uses).
-    PCIe-bound: measured against ONE pinned device-to-host hipMemcpy of the same bytes on this box."""
-    import shutil
-    import tempfile
-    import wave
-    from afskmodem_amd import batch
-    torch = ctx.torch
-    d = bench_tmpdir("afsk_bench_out_", 2 * n_files * 96044)
-    try:
-        x = torch.randint(-32768, 32767, (n_files * STREAM_LEN,), dtype=torch.int16, device=ctx.dev)
-        offs = np.arange(n_files, dtype=np.int64) * STREAM_LEN
-        lens = np.full(n_files, STREAM_LEN, np.int32)
-        # a corpus spread over 64 directories, and -- `one_directory` -- flat (on a disk-backed file system the two
-        # differ a lot, on tmpfs hardly)
-        for k in range(64):
-            os.mkdir(os.path.join(d, f"d{k:02d}"))
-        names = [os.path.join(d, f"d{i % 64:02d}", f"o{i:05d}.wav") for i in range(n_files)]
-        flat_names = [os.path.join(d, f"o{i:05d}.wav") for i in range(n_files)]
-        torch.cuda.synchronize()
-        assert (batch.save_wav_batch(x, offs, lens, names) == 0).all()             # warm: creates the files
-        ts, ts_over, ts_flat = [], [], []
-        for _ in range(reps):                                  # NEW files: what a pipeline that produces a corpus does
-            for fn in names:
-                os.unlink(fn)
-            t0 = time.perf_counter()
-            st = batch.save_wav_batch(x, offs, lens, names)
-            ts.append(time.perf_counter() - t0)
-        for _ in range(max(2, reps // 2)):                     # NEW files, all in one directory
-            t0 = time.perf_counter()
-            batch.save_wav_batch(x, offs, lens, flat_names)
-            ts_flat.append(time.perf_counter() - t0)
-            for fn in flat_names:
-                os.unlink(fn)
-        for _ in range(reps):                                  # existing files of the same size, overwritten in place
-            t0 = time.perf_counter()
-            batch.save_wav_batch(x, offs, lens, names)
-            ts_over.append(time.perf_counter() - t0)
-        total_bytes = n_files * STREAM_LEN * 2
-        pin = torch.empty(total_bytes // 2, dtype=torch.int16, pin_memory=True)
-        pin.copy_(x, non_blocking=True)
-        torch.cuda.synchronize()
-        pc = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            pin.copy_(x, non_blocking=True)
-            torch.cuda.synchronize()
-            pc.append(time.perf_counter() - t0)
-        ok = 0
-        pick = list(range(0, n_files, max(1, n_files // 64)))
-        for i in pick:
-            with wave.open(names[i], "rb") as f:
-                raw = f.readframes(f.getnframes())
-            ok += raw == x[i * STREAM_LEN: (i + 1) * STREAM_LEN].cpu().numpy().tobytes()
-        med, peak = median(ts), total_bytes / min(pc) / 1e9
-        return {"row": "f5 .wav egress (afsk_wav_egress: device streams -> files)", "files": n_files, "bytes": total_bytes,
-                "reps": reps, "unit": "files/s", "value": round(n_files / med), "all_status_ok": bool((st == 0).all()),
-                "egress_ms": {"median": round(med * 1e3, 3), "best": round(min(ts) * 1e3, 3)},
-                "egress_overwrite_in_place_ms": {"median": round(median(ts_over) * 1e3, 3), "best": round(min(ts_over) * 1e3, 3)},
-                "egress_new_files_one_directory_ms": {"median": round(median(ts_flat) * 1e3, 3), "best": round(min(ts_flat) * 1e3, 3)},
-                "pinned_hipMemcpy_d2h_ms": round(min(pc) * 1e3, 3), "decoded_match_rate": ok / len(pick),
-                "roofline": {"bound": "pcie", "achieved": round(total_bytes / med / 1e9, 2), "peak": round(peak, 2), "unit": "GB/s",
-                             "frac": round(total_bytes / med / 1e9 / peak, 4), "traffic": None,
-                             "algorithmic_bytes_per_launch": total_bytes, "kernel_ms": round(med * 1e3, 3),
-                             "frac_overwrite_in_place": round(total_bytes / median(ts_over) / 1e9 / peak, 4),
-                             "bound_note": "NEW files spread over 64 directories (frac) / existing files overwritten in place (frac_overwrite_in_place); "
-                                           "device -> host link: peak = one pinned hipMemcpy of the same bytes measured in this run; "
-                                           "for new files the kernel's page allocation (24 pages per file), not the link, is the limit"},
-                "files_on": os.path.dirname(d)}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-
-
-def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_streams: int = 64, warmup: int = 10) -> dict:
-    """4096 x 1 s clean streams at EVERY rate a Receiver can be built for (bit_frames must divide 48000 and
-    be a multiple of 4: 36 values, 12000 ... 24 baud), each through its own uniform kernel: time per launch,
-    fraction of the HBM peak in algorithmic bytes, round trip to the modulated payloads and the CPU oracle
-    on a sample.  (Below ~100 baud a 1 s stream holds 0 - 2 payload bytes: training, terminator and tail.)"""
-    rows = {}
-    cores = usable_cpus()
-    for baud in ALL_RATES:
-        sh = Shard(ctx, "custom", n_streams, bauds=(baud,), desc=f"{n_streams} streams x 1 s @{baud} baud, clean")
-        # 50 ms pre-roll: every rate starts from settled clocks; the figure is the MEDIAN of three K-step regions
-        # (single regions of one rate differ by +-0.03 from run to run)
-        rec, aux = measure(ctx, sh, steps, warmup, 50.0, 0, 3.0 * steps * (0.9 if n_streams >= 32768 else 0.06), 3)
-        row = {"bit_frames": 48000 // baud, "payload_bytes": int(sh.plen_h[0]), "entry": rec["entry"],
-               "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
-               "kernel_ms_median": rec["roofline"]["kernel_ms_median"], "frac": rec["roofline"]["frac"],
-               "frac_at_median": rec["roofline"]["frac_at_median"],
-               "algorithmic_bytes_per_launch": rec["roofline"]["algorithmic_bytes_per_launch"],
-               "full_buffer_gbs": rec["roofline"]["full_buffer_gbs"],
-               "roundtrip_match_rate": rec["roundtrip_match_rate"],
-               "all_timed_steps_identical": rec["all_timed_steps_identical"]}
-        if not ctx.args.no_cpu_baseline:
-            row["match_rate"], _, _ = oracle_match(sh, aux["res"], aux["got_payloads"], sh.inputs[0],
-                                                   min(check_streams, n_streams), cores)
-        rows[str(baud)] = row
-        # (no empty_cache(): the next rate's 6.29 GB buffer is the block this one gives back to torch's caching
-        # allocator.  A FRESHLY hipMalloc'ed buffer streams 2-4 % slower for its first seconds -- tools/order_probe.py:
-        # 0.824 right after allocation, 0.841 for the same buffer ten seconds later -- and that is not what
-        # "inputs resident in HBM" means.)
-        del sh, aux
-    fr = [r["frac"] for r in rows.values()]
-    slow = sorted(rows, key=lambda b: rows[b]["frac"])[:3]
-    doc = {"row": f"{n_streams} x 1 s clean streams at each of the {len(rows)} rates a Receiver can be built for "
-                  "(afsk_demod_batch_uniform: one kernel per bit_frames)",
-           "steps": steps, "min_frac": min(fr), "max_frac": max(fr), "median_frac": median(fr),
-           "rates_below_0.60": [b for b, r in rows.items() if r["frac"] < 0.60],
-           "rates_below_0.75": [b for b, r in rows.items() if r["frac"] < 0.75],
-           "slowest": {b: rows[b]["frac"] for b in slow},
-           "all_round_trips_exact": all(r["roundtrip_match_rate"] == 1.0 for r in rows.values()),
-           "by_baud": rows}
-    if not ctx.args.no_cpu_baseline:
-        doc["min_match_rate"] = min(r["match_rate"] for r in rows.values())
-    return doc
+    # (the line says where the figure comes from: a committed PMC pass of the same kernel source, not this run)
+    rf["traffic_source"] = f"profiles/traffic_latest.json@{src_hash} (rocprofv3 --pmc passes of {ent.get('source')}; not measured in this run)"
 
 
 def cpu_calibration() -> dict | None:
@@ -1114,8 +1174,10 @@ _LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_st
               "vs_baseline", "dtype", "data", "config", "entry", "timed_regions", "timed_region_ms",
               "event_ms_per_step_median", "kernel_source_hash", "roundtrip_match_rate", "all_timed_steps_identical",
               "match_rate", "match_sample_streams", "per_workload_value", "ranks_seen", "gather_mode", "gather_check",
-              "gather_check_on_every_rank", "gather_every_steps", "gathers_in_timed_region")
-_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms")
+              "gather_check_on_every_rank", "gather_every_steps", "gathers_in_timed_region",
+              "value_no_gather", "ms_per_step_no_gather", "frac_no_gather", "host_threads_per_rank")
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+              "kernel_ms")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "single_thread_value", "python_reference_shaped_value",
              "calibration")
 
@@ -1126,6 +1188,8 @@ def _pick(d: dict, keys) -> dict:
 
 def _sub_summary(name: str, rec: dict) -> dict:
     """One sub-record reduced to {value, frac, match_rate} (+ the two or three figures that only it has)."""
+    if "error" in rec and "roofline" not in rec:
+        return {"error": str(rec["error"])[:120]}                        # a rider that failed: said so, nothing else
     if "roofline" not in rec and all(isinstance(v, dict) for v in rec.values()):
         return {k: _sub_summary(k, v) for k, v in rec.items()}          # f2_gate: one entry per capture count
     if "by_baud" in rec:                                                 # rates_4096 / rates_65536
@@ -1169,7 +1233,7 @@ def compact_line(full: dict, full_path: str | None = None) -> dict:
     if "gather_ms" in full:
         line["gather_ms"] = _pick(full["gather_ms"], ("median", "max", "bytes_per_rank"))
     if "headline_again_at_end" in full:
-        line["headline_again_at_end"] = _pick(full["headline_again_at_end"], ("value", "frac"))
+        line["headline_again_at_end"] = _pick(full["headline_again_at_end"], ("value", "frac", "error"))
     if full.get("sub_records"):
         line["sub_records"] = {k: _sub_summary(k, v) for k, v in full["sub_records"].items()}
     line["full_record"] = full_path
@@ -1178,7 +1242,20 @@ def compact_line(full: dict, full_path: str | None = None) -> dict:
         if len(json.dumps(line)) < LINE_CAP:
             break
         line[victim] = "see full_record"
-    assert len(json.dumps(line)) < LINE_CAP, "bench line over the cap"
+    if len(json.dumps(line)) >= LINE_CAP:
+        # last resort (never an exception after a multi-minute run): the contract's keys, the roofline and the
+        # pointer to the full record -- a parseable line is always printed
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "value_no_gather", "ranks_seen")
+        slim = _pick(line, keep)
+        slim["config"] = _pick(line.get("config") or {}, ("workload", "streams_per_gpu", "streams_total", "parallelism"))
+        slim["roofline"] = _pick(line.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+        if "cpu_baseline" in line:
+            slim["cpu_baseline"] = _pick(line["cpu_baseline"], ("value", "unit", "cores", "kind"))
+            slim["cpu_baseline"]["sample"] = "see full_record"
+        slim["full_record"] = full_path
+        slim["line_note"] = "summaries dropped: the compact line would have exceeded the cap"
+        line = slim
     return line
 
 
@@ -1199,10 +1276,44 @@ def write_full_record(full: dict, world: int, tag: str = "") -> str | None:
 
 
 def run_rank(args) -> None:
-    ctx = Ctx(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    hb = Heartbeat(rank, world)
+    deadline_s = args.deadline_s
+    if os.environ.get("AFSK_BENCH_LAUNCHER") == "1" and deadline_s > 0:
+        deadline_s += 15.0            # bench.py's own launcher holds the clock; this is only the backstop behind it
+    dog = Watchdog(hb, args, deadline_s)
+    try:
+        _run_rank(args, hb, dog)
+    except BaseException as e:  # noqa: BLE001
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        # an ordinary Python error on this rank: say so in the line (rank 0) or on stderr, exit non-zero --
+        # torchrun / the launcher then terminates the other ranks, whose watchdogs stand by
+        import traceback
+        tb = traceback.format_exc()
+        sys.stderr.write(tb)
+        why = f"{type(e).__name__}: {e}"
+        last = hb.phase
+        hb.quiet = True
+        hb.beat(f"failed in '{last}': {why}"[:200])
+        dog.stand_down()
+        if not dog.under_launcher and rank == 0:
+            hbs = read_heartbeats(hb.dir, world)
+            print(json.dumps(failure_line(world, args.steps, args.warmup, f"rank 0: {why}", last, hbs,
+                                          read_partial(hb.dir), "rank 0")), flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(EXIT_RANK_FAILED if not isinstance(e, SystemExit) else (e.code if isinstance(e.code, int) else 2))
+
+
+def _run_rank(args, hb: Heartbeat, dog: Watchdog) -> None:
+    ctx = Ctx(args, hb)
     torch, dist = ctx.torch, ctx.dist
     world, rank = ctx.world, ctx.rank
-    cores = usable_cpus()
+    cores = usable_cpus()               # this rank's share of the box (LOCAL_WORLD_SIZE ranks per node)
+    os.environ.setdefault("AFSK_IO_THREADS", str(min(32, cores)))     # libafsk_amd.so's I/O pool, same share
+    os.environ.setdefault("AFSK_COPY_THREADS", str(min(16, cores)))
     src_hash = kernel_source_hash()
 
     pl = plan(world, args.workload, args.sub, args.streams)
@@ -1212,8 +1323,21 @@ def run_rank(args) -> None:
         return args.streams if args.streams > 0 else WORKLOADS[name][0]
 
     # ---------------- main record
+    hb.beat(f"building the {main_name} shard ({n_for(main_name)} streams)")
     sh = Shard(ctx, main_name, n_for(main_name))
-    rec, aux = measure(ctx, sh, args.steps, args.warmup, args.preroll_ms, args.gather_every, args.min_region_ms)
+    hb.beat("shard built")
+    rec_ng = None
+    if ctx.comm is not None and not args.no_value_no_gather:
+        # N > 1: the SAME K-step regions first without the exchange of the decoded records ...
+        hb.beat("timing without the gather")
+        rec_ng, _ = measure(ctx, sh, args.steps, args.warmup, args.preroll_ms, args.gather_every, args.min_region_ms,
+                            with_gather=False)
+        hb.beat("timed without the gather")
+    # ... then (the headline) with it: every step's records are exchanged inside the timed region
+    hb.beat("warm-up + timed region")
+    rec, aux = measure(ctx, sh, args.steps, args.warmup, args.preroll_ms if rec_ng is None else min(args.preroll_ms, 50.0),
+                       args.gather_every, args.min_region_ms)
+    hb.beat("timed" + (" and gathered" if ctx.comm is not None else ""))
     attach_traffic(rec, main_name, sh.n_local, src_hash)
     out = {
         "metric": METRIC,
@@ -1246,28 +1370,74 @@ def run_rank(args) -> None:
         "checked_step": rec["checked_step"],
         "all_timed_steps_identical": rec["all_timed_steps_identical"],
         "host_issue_ms_per_step": rec["host_issue_ms_per_step"],
+        "host_threads_per_rank": cores,
     }
     out["config"]["bauds"] = list(sh.bauds)       # (--workload custom --bauds ... replaces the table entry)
     for k in ("ranks_seen", "gather_mode", "gather_check", "gather_check_on_every_rank", "gather_every_steps",
               "gathers_in_timed_region", "gather_ms"):
         if k in rec:
             out[k] = rec[k]
+    if rec_ng is not None:
+        out["value_no_gather"] = rec_ng["value"]
+        out["ms_per_step_no_gather"] = rec_ng["ms_per_step"]
+        out["frac_no_gather"] = rec_ng["roofline"]["frac"]
+        out["roundtrip_match_rate_no_gather"] = rec_ng["roundtrip_match_rate"]
+    full_path = [None]
+    tag = args.workload or ("partial" if (args.sub is not None or args.streams) else "")
+
+    def checkpoint(note: str) -> None:
+        """Rank 0: from here on a line with numbers exists whatever happens to the riders -- the launcher or the
+        watchdog prints this snapshot (marked incomplete) if the run dies or runs out of time later."""
+        if rank != 0:
+            return
+        snap = dict(out)
+        if subs:
+            snap["sub_records"] = dict(subs)
+        snap["per_workload_value"] = dict(per_workload)
+        line = compact_line(snap, full_path[0])
+        line["riders_pending"] = note
+        hb.write_partial(line)
+
+    subs: dict = {}
+    per_workload = {main_name: out["value"]}
+    checkpoint("everything after the headline")
+
+    def rider(name: str, fn):
+        """A sub-record that fails (or its import) becomes {"error": ...}: it can never cost the headline."""
+        hb.beat(f"sub-record {name}")
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            sys.stderr.write(f"bench.py: sub-record {name} failed:\n{traceback.format_exc()}")
+            if ctx.use_dist:
+                raise             # at N > 1 a rank that skips a rider's collectives would hang the others: fail the run
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if world == 1 and not args.no_cpu_baseline:
+        hb.beat("cpu_baseline (CPU oracle on the host cores)")
         ns = args.cpu_sample_streams or min(sh.n_local, 4096)
         out["cpu_baseline"], out["match_rate"], out["match_sample_streams"] = cpu_baseline_for(
             sh, aux["res"], aux["got_payloads"], ns, cores, args.cpu_budget_s, label=" (the first of them)")
-    subs = {}
+        checkpoint("every sub-record")
     # the next rows that reuse the headline shard's buffers: f1 re-writes its input, f2 reads it
-    if world == 1 and "f1_modulate" in next_rows:
-        subs["f1_modulate"] = measure_modulate(ctx, sh, args.next_reps)
-    if world == 1 and "f2_gate" in next_rows:
-        subs["f2_gate"] = {"captures_%d" % sh.n_local: measure_gate(ctx, sh, args.next_reps)}
-    del sh, aux            # (back to torch's caching allocator, NOT to the driver: see measure_rates)
+    if world == 1 and ("f1_modulate" in next_rows or "f2_gate" in next_rows):
+        def _rows():
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_rows
+            return bench_rows
+        if "f1_modulate" in next_rows:
+            subs["f1_modulate"] = rider("f1_modulate", lambda: _rows().measure_modulate(ctx, sh, args.next_reps))
+        if "f2_gate" in next_rows:
+            subs["f2_gate"] = {"captures_%d" % sh.n_local: rider("f2_gate", lambda: _rows().measure_gate(ctx, sh, args.next_reps))}
+    del sh, aux            # (back to torch's caching allocator, NOT to the driver: see bench_rows.measure_rates)
 
     # ---------------- sub-records: the other single-GPU configs in the same line
-    per_workload = {main_name: out["value"]}
-    for name in sub_names:
+    def config_sub(name: str) -> dict:
         n_local = n_for(name)
         big = n_local * STREAM_LEN * 2 >= (1 << 30)
         s_steps = args.sub_steps or (20 if big else 200)
@@ -1294,37 +1464,52 @@ def run_rank(args) -> None:
                 srec["ber_curve"] = ber_curve(ctx, shs, ns, cores)
                 shs.regenerate(shs.snr_db)
         if world == 1 and "f2_gate" in next_rows and name == "config2":
-            subs.setdefault("f2_gate", {})["captures_%d" % n_local] = measure_gate(ctx, shs, max(args.next_reps, 50))
-        per_workload[name] = srec["value"]
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_rows
+            subs.setdefault("f2_gate", {})["captures_%d" % n_local] = bench_rows.measure_gate(ctx, shs, max(args.next_reps, 50))
+        return srec
+
+    for name in sub_names:
+        srec = rider(name, lambda: config_sub(name))
+        per_workload[name] = srec.get("value")
         subs[name] = srec
-        del shs, saux
-    if world == 1 and "f3_wav_ingest" in next_rows:
-        subs["f3_wav_ingest"] = measure_wav_ingest(ctx, args.wav_files)
-    if world == 1 and "f5_wav_egress" in next_rows:
-        subs["f5_wav_egress"] = measure_wav_egress(ctx, args.wav_files)
-    # (the steady-state table first: it follows the host-bound file rows, during which the GPU idles, so its 36
-    # workloads start from a state closer to the headline's than after the 36 prerolls of the 4096-stream table)
-    for row, n_str in sorted(RATES_ROWS.items(), key=lambda kv: -kv[1]):
-        if world == 1 and row in next_rows:
-            big = n_str >= 32768
-            subs[row] = measure_rates(ctx, args.rates_steps or (20 if big else 120), n_str, warmup=3 if big else 10)
+        checkpoint(f"sub-records after {name}")
+    if world == 1 and next_rows:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        if "f3_wav_ingest" in next_rows:
+            subs["f3_wav_ingest"] = rider("f3_wav_ingest", lambda: __import__("bench_rows").measure_wav_ingest(ctx, args.wav_files))
+        if "f5_wav_egress" in next_rows:
+            subs["f5_wav_egress"] = rider("f5_wav_egress", lambda: __import__("bench_rows").measure_wav_egress(ctx, args.wav_files))
+        checkpoint("the per-rate tables")
+        # (the steady-state table first: it follows the host-bound file rows, during which the GPU idles, so its 36
+        # workloads start from a state closer to the headline's than after the 36 prerolls of the 4096-stream table)
+        for row, n_str in sorted(RATES_ROWS.items(), key=lambda kv: -kv[1]):
+            if row in next_rows:
+                big = n_str >= 32768
+                subs[row] = rider(row, lambda: __import__("bench_rows").measure_rates(
+                    ctx, args.rates_steps or (20 if big else 120), n_str, warmup=3 if big else 10))
+                checkpoint(f"what follows {row}")
     if world == 1 and subs and not args.workload and args.sub is None:
         # The headline is necessarily the first allocation of the process, and a given 6.29 GB allocation streams at its
         # own rate (+-2 %: tools/order_probe.py).  Here the same workload is measured AGAIN, last, in a recycled buffer
         # like every sub-record -- reported next to the headline, never instead of it.
-        shl = Shard(ctx, main_name, n_for(main_name))
-        lrec, _ = measure(ctx, shl, args.steps, args.warmup, 50.0, 0, args.min_region_ms)
-        out["headline_again_at_end"] = {"value": lrec["value"], "ms_per_step": lrec["ms_per_step"],
-                                        "frac": lrec["roofline"]["frac"], "kernel_ms": lrec["roofline"]["kernel_ms"],
-                                        "roundtrip_match_rate": lrec["roundtrip_match_rate"],
-                                        "note": "the headline workload measured again after all sub-records, in a recycled buffer"}
-        del shl
+        def again():
+            shl = Shard(ctx, main_name, n_for(main_name))
+            lrec, _ = measure(ctx, shl, args.steps, args.warmup, 50.0, 0, args.min_region_ms)
+            return {"value": lrec["value"], "ms_per_step": lrec["ms_per_step"],
+                    "frac": lrec["roofline"]["frac"], "kernel_ms": lrec["roofline"]["kernel_ms"],
+                    "roundtrip_match_rate": lrec["roundtrip_match_rate"],
+                    "note": "the headline workload measured again after all sub-records, in a recycled buffer"}
+        out["headline_again_at_end"] = rider("headline_again_at_end", again)
     if subs:
         out["sub_records"] = subs
     out["per_workload_value"] = per_workload
     out["scaling_note"] = ("the headline workload is the config5 shard (65536 streams x 1 s @1200 baud per GPU, what north_star "
-                           "names) at EVERY N: value(N) / (N * value(1)) is the weak-scaling efficiency; config2 / config3 / "
-                           "config4 and the SURVEY 8(f) rows f1 / f2 / f3 ride along as sub_records at N = 1, the config2 shard at N > 1")
+                           "names) at EVERY N: value(N) / (N * value(1)) is the weak-scaling efficiency; value_no_gather is the "
+                           "same K-step regions without the exchange of the decoded records, gather_ms the duration of one "
+                           "collective; config2 / config3 / config4, the SURVEY 8(f) rows f1 / f2 / f3 and rates_65536 ride along "
+                           "as sub_records at N = 1 (f5_wav_egress and rates_4096: --sub), the config2 shard at N > 1")
+    hb.beat("closing the process group" if ctx.use_dist else "writing the result")
     if ctx.use_dist:
         dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit,
@@ -1333,11 +1518,15 @@ def run_rank(args) -> None:
         C.CDLL(None).fflush(None)
     except Exception:  # noqa: BLE001
         pass
+    dog.stand_down()
     if rank == 0:
         # only the default run (headline + every rider) writes bench_full_n<N>.json; side runs get their own file
-        tag = args.workload or ("partial" if (args.sub is not None or args.streams) else "")
         path = write_full_record(out, world, tag)
         print(json.dumps(compact_line(out, path)), flush=True)
+    hb.beat("done")
+    if rank == 0 and os.environ.get("AFSK_BENCH_LAUNCHER") != "1":
+        import shutil
+        shutil.rmtree(hb.dir, ignore_errors=True)
 
 
 def main() -> None:
@@ -1381,6 +1570,14 @@ def main() -> None:
                     help="diagnostic: all ranks on device 0 (needs --dist-backend gloo), to exercise the N > 1 flow on a 1-GPU box")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the RCCL gather path even at N=1 (single-rank group); diagnostics")
+    ap.add_argument("--deadline-s", type=float, default=420.0,
+                    help="wall-clock limit of the whole run (launcher: over its rank children; a rank: from its own start). "
+                         "When it passes, ONE JSON line says what every rank was doing -- with the headline's numbers if it "
+                         "had been measured -- and the exit code is non-zero.  0 = no limit")
+    ap.add_argument("--pg-timeout-s", type=float, default=90.0,
+                    help="torch.distributed process-group timeout: rendezvous and every collective")
+    ap.add_argument("--no-value-no-gather", action="store_true",
+                    help="N > 1: skip the extra K-step regions without the gather (value_no_gather)")
     args = ap.parse_args()
 
     global RATE_ORDER
@@ -1389,10 +1586,9 @@ def main() -> None:
         bl = tuple(int(b) for b in args.bauds.split(","))
         WORKLOADS["custom"] = (WORKLOADS["custom"][0], bl, None, f"custom: streams x 1 s, clean, bauds {list(bl)}, per GPU")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        # bare `python bench.py --gpus N`: become the launcher.  Nothing above or below this line
-        # touches the GPU in this process (device_count() does not initialise it on this image).
-        import torch
-        have = torch.cuda.device_count()
+        # bare `python bench.py --gpus N`: become the launcher.  This process never touches the GPU and never
+        # imports torch: the devices are counted in sysfs (KFD topology).
+        have = visible_gpus()
         if args.share_gpu0 and args.dist_backend != "gloo":
             sys.stderr.write("bench.py: --share-gpu0 needs --dist-backend gloo (RCCL refuses two ranks on one device)\n")
             raise SystemExit(2)
@@ -1400,12 +1596,13 @@ def main() -> None:
             sys.stderr.write(f"bench.py: --share-gpu0 runs at most {SHARE_GPU0_MAX_RANKS} ranks (the GPU boxes allow "
                              "6 processes per device, and the caller of this diagnostic usually holds the device too)\n")
             raise SystemExit(2)
-        if have < (1 if args.share_gpu0 else args.gpus):
+        if have is not None and have < (1 if args.share_gpu0 else args.gpus):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible\n")
             raise SystemExit(2)
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], deadline_s=args.deadline_s, steps=args.steps, warmup=args.warmup))
     run_rank(args)
 
 
 if __name__ == "__main__":
+    sys.modules.setdefault("bench", sys.modules["__main__"])   # tools/bench_rows.py imports this module by name
     main()

@@ -610,6 +610,53 @@ def main():
     with open(fn, "rb") as f:
         G["readme_wav_file_sha256"] = hashlib.sha256(f.read()).hexdigest()
 
+    # ---- 7. degenerate constructor arguments (ref:69-76, 277, 438, 457): negative rates build EMPTY templates
+    # (range(negative)), a negative training time builds zero training cycles; what each call then does is
+    # recorded from the reference itself (r5: the host mirror raised numpy errors for these)
+    def outcome(fn_):
+        try:
+            return fn_()
+        except BaseException as e:  # noqa: BLE001
+            return f"raises {type(e).__name__}: {e}"
+
+    deg = {"bauds": {}, "training_time": []}
+    long_frames = ref.Transmitter(1200)._Transmitter__getFrames(b"Hi!")
+    for baud in (-1200, -300, -2400, -12000, -48000, -96000, -700, -7, 0):
+        ent = {}
+        ent["space"] = outcome(lambda: ref.Waveforms.getSpaceTone(baud))
+        ent["mark"] = outcome(lambda: ref.Waveforms.getMarkTone(baud))
+        ent["training"] = outcome(lambda: ref.Waveforms.getTrainingCycle(baud))
+        ent["receiver"] = outcome(lambda: "ok" if ref.Receiver(baud) else "ok")
+        ent["transmitter"] = outcome(lambda: "ok" if ref.Transmitter(baud) else "ok")
+        if ent["transmitter"] == "ok":
+            t = ref.Transmitter(baud)
+            fr = outcome(lambda: t._Transmitter__getFrames(b"Hi!"))
+            ent["frames"] = fr if isinstance(fr, str) else {"n_frames": len(fr), "frames_sha256": sha(fr)}
+            fn = os.path.join(tmpdir, f"neg{abs(baud)}.wav")
+            ent["save"] = outcome(lambda: (t.save(b"Hi!", fn), hashlib.sha256(open(fn, "rb").read()).hexdigest())[1])
+        if ent["receiver"] == "ok":
+            r = ref.Receiver(baud)
+            for tag, frames in (("decode_4000", long_frames[:4000]), ("decode_4096", long_frames[:4096]),
+                                ("decode_full", long_frames), ("decode_empty", [])):
+                got = outcome(lambda: r._Receiver__decodeBits(list(frames)))
+                ent[tag] = got if got.startswith("raises") else "bits:" + got
+            fn = os.path.join(tmpdir, "neg_in.wav")
+            ref.Transmitter(1200).save(b"Hi!", fn)
+            got = outcome(lambda: r.load(fn, False))
+            ent["load_1200_baud_file"] = got if isinstance(got, str) else "bytes:" + got.hex()
+        deg["bauds"][str(baud)] = ent
+    for baud, tt in ((1200, -1.0), (1200, -0.001), (300, -0.5), (2400, -100.0), (1200, 0.0)):
+        t = ref.Transmitter(baud, tt)
+        fr = t._Transmitter__getFrames(b"Hi!")
+        wav = np.frombuffer(ref.SoundOutput._SoundOutput__convertFrames(fr), dtype="<i2")
+        fn = os.path.join(tmpdir, "negtt.wav")
+        t.save(b"Hi!", fn)
+        got = outcome(lambda: ref.Receiver(baud).load(fn, False))
+        deg["training_time"].append({"baud": baud, "training_time": tt, "ts_cycles": t._Transmitter__ts_cycles,
+                                     "n_frames": len(fr), "frames_sha256": sha(fr), "n_wav": len(wav), "wav_sha256": sha(wav),
+                                     "load": got if isinstance(got, str) else "bytes:" + got.hex()})
+    G["degenerate_api"] = deg
+
     out = os.path.join(HERE, "reference_vectors.json")
     with open(out, "w") as f:
         json.dump(G, f, separators=(",", ":"))

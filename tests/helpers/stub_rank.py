@@ -1,6 +1,8 @@
 """Stand-in for bench.py's rank side (CPU, gloo): lets tests/test_bench_launch.py exercise the
-launcher half of `bench.py --gpus N` -- N processes under torch.distributed.run, rank 0's JSON
-line relayed, a failing rank turning into a non-zero exit code -- without a GPU."""
+launcher half of `bench.py --gpus N` -- N rank processes, rank 0's JSON line relayed, a failing or
+hanging rank turning into ONE diagnostic line and a non-zero exit code -- without a GPU.
+Modes: ok | fail (last rank dies after the first collective) | silent (no line) | hang (last rank never
+arrives at the barrier) | hang_after_headline (rank 0 has checkpointed a partial line, then the last rank hangs)."""
 import json
 import os
 import sys
@@ -11,14 +13,27 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402  (plan / config_block: the same pure functions bench.run_rank builds its line from)
 
+import time  # noqa: E402
+
 mode = sys.argv[1] if len(sys.argv) > 1 else "ok"
+hb = bench.Heartbeat(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+hb.beat("pg up")
 ones = torch.ones(1, dtype=torch.int32)
 dist.all_reduce(ones)
 print(f"noise from rank {rank}", flush=True)
 if mode == "fail" and rank == world - 1:
+    hb.beat("about to die")
     os._exit(3)
+if mode == "hang_after_headline" and rank == 0:
+    hb.write_partial({"metric": "stub", "value": 123.0, "unit": "Msamples/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                      "ms_per_step": 1.0, "roofline": {"frac": 0.5}, "riders_pending": "config2"})
+    hb.beat("sub-record config2")
+if mode in ("hang", "hang_after_headline") and rank == world - 1:
+    hb.beat("stuck before the barrier")
+    time.sleep(3600)
+dist.barrier()                # (a dead or hanging rank: rank 0 waits here, no result line can come out of the run)
 if mode != "silent" and rank == 0:
     pl = bench.plan(world)
     # a full record shaped like run_rank's at N > 1 (figures are placeholders), through the SAME compaction

@@ -23,12 +23,19 @@ def bench_mod():
     return bench
 
 
-def _launch(mode):
+def _launch(mode, **kw):
     import bench
     buf = io.StringIO()
     with redirect_stdout(buf):
-        rc = bench.self_launch(2, [mode], script=STUB)
+        rc = bench.self_launch(2, [mode], script=STUB, **kw)
     return rc, buf.getvalue()
+
+
+def _one_line(out):
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out                      # ONE JSON line on stdout whatever happened
+    assert len(lines[0]) < bench_mod().LINE_CAP
+    return json.loads(lines[0])
 
 
 def test_launcher_relays_rank0_line_only():
@@ -45,14 +52,166 @@ def test_launcher_relays_rank0_line_only():
     assert doc["sub_records"]["config2"]["gather_check"] is True
 
 
-def test_launcher_nonzero_when_a_rank_fails():
-    rc, _ = _launch("fail")
-    assert rc != 0
+def test_launcher_says_which_rank_died():
+    """A rank that dies: the launcher terminates the others (rank 0 sits in a barrier that will never complete)
+    and prints ONE line that names the rank, its exit code and every rank's last heartbeat -- quickly."""
+    import time
+    t0 = time.monotonic()
+    rc, out = _launch("fail", deadline_s=120.0, steps=7, warmup=3)
+    took = time.monotonic() - t0
+    doc = _one_line(out)
+    assert rc == bench_mod().EXIT_RANK_FAILED and took < 60, (rc, took)
+    assert doc["value"] is None and doc["n_gpus"] == 2 and doc["steps"] == 7 and doc["warmup"] == 3
+    assert doc["metric"] == bench_mod().METRIC and "rank 1 -> exit code 3" in doc["error"]
+    assert doc["heartbeats"]["1"]["phase"] == "about to die" and doc["heartbeats"]["0"]["phase"] == "pg up"
+    assert doc["phase"] == "pg up" and doc["printed_by"] == "launcher"
+
+
+def test_launcher_deadline_on_a_hanging_rank():
+    """A rank that never arrives: after --deadline-s the launcher kills every rank and the line says who was where."""
+    import time
+    t0 = time.monotonic()
+    rc, out = _launch("hang", deadline_s=8.0, grace_s=2.0)
+    took = time.monotonic() - t0
+    doc = _one_line(out)
+    assert rc == bench_mod().EXIT_DEADLINE and took < 40, (rc, took)
+    assert doc["value"] is None and "deadline of 8 s" in doc["error"] and "1" in doc["error"]
+    assert doc["heartbeats"]["1"]["phase"] == "stuck before the barrier"
+    assert doc["heartbeats"]["0"]["age_s"] is not None
+
+
+def test_launcher_keeps_the_headline_when_a_rider_hangs():
+    """Once rank 0 has checkpointed a line with numbers, a later hang costs the riders, not the headline."""
+    rc, out = _launch("hang_after_headline", deadline_s=8.0, grace_s=2.0)
+    doc = _one_line(out)
+    assert rc == bench_mod().EXIT_DEADLINE
+    assert doc["value"] == 123.0 and doc["incomplete"] is True and doc["riders_pending"] == "config2"
+    assert "deadline" in doc["error"] and doc["heartbeats"]["0"]["phase"] == "sub-record config2"
 
 
 def test_launcher_nonzero_without_a_result_line():
     rc, out = _launch("silent")
-    assert rc != 0 and out.strip() == ""
+    doc = _one_line(out)
+    assert rc == bench_mod().EXIT_NO_LINE and doc["value"] is None and "no result line" in doc["error"]
+
+
+def test_rank_watchdog_prints_the_line_under_an_external_launcher(tmp_path):
+    """The driver launches the ranks with torch.distributed.run itself: then no bench.py launcher exists and the
+    in-rank watchdog must produce the line.  Rank 1 hangs in its main thread (a sleep stands in for a collective
+    that never completes), the deadline passes, rank 0's watchdog thread prints and both exit non-zero."""
+    code = (
+        "import os, sys, time, types\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "rank = int(os.environ['RANK'])\n"
+        "hb = bench.Heartbeat(rank, 2)\n"
+        "args = types.SimpleNamespace(steps=5, warmup=1)\n"
+        "dog = bench.Watchdog(hb, args, 3.0)\n"
+        "hb.beat('pg up')\n"
+        "if rank == 0: hb.beat('warm-up + timed region')\n"
+        "time.sleep(600)\n")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999",
+               AFSK_BENCH_HB_DIR=str(tmp_path))
+    env.pop("AFSK_BENCH_LAUNCHER", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert [p.returncode for p in procs] == [bench_mod().EXIT_DEADLINE] * 2
+    assert outs[1][0].strip() == ""                                   # only one rank prints
+    doc = _one_line(outs[0][0])
+    assert doc["printed_by"] == "rank 0" and doc["value"] is None and doc["n_gpus"] == 2 and doc["steps"] == 5
+    assert "deadline of 3 s" in doc["error"] and doc["phase"].startswith("warm-up + timed region [main thread at")
+    assert doc["heartbeats"]["1"]["phase"].startswith("aborted in 'pg up'") or doc["heartbeats"]["1"]["phase"] == "pg up"
+
+
+def test_rank_watchdog_sigterm_while_the_main_thread_is_stuck(tmp_path):
+    """torchrun terminates the survivors of a failed rank with SIGTERM.  The main thread may sit in a C call that
+    never returns to the interpreter (here: a blocking read on a pipe nobody writes to, through ctypes), so a Python
+    signal handler would never run -- the watchdog thread still prints the line and ends the process.
+    Rank 0 is gone (its heartbeat names a dead pid): the surviving rank 1 takes over the printing."""
+    import signal
+    import time
+    code = (
+        "import os, sys, time, types, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "hb = bench.Heartbeat(1, 2)\n"
+        "dog = bench.Watchdog(hb, types.SimpleNamespace(steps=5, warmup=1), 300.0)\n"
+        "hb.beat('timed without the gather')\n"
+        "r, w = os.pipe()\n"
+        "print('READY', file=sys.stderr, flush=True)\n"
+        "while True:\n"          # (a C loop that retries on EINTR, like a collective's progress loop)
+        "    ctypes.CDLL(None).read(r, ctypes.create_string_buffer(8), 8)\n")
+    (tmp_path / "rank0.json").write_text(json.dumps({"rank": 0, "pid": 2 ** 22 + 12345, "phase": "shard built",
+                                                     "t": time.time(), "t_start": time.time(), "since_start_s": 1.0}))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", AFSK_BENCH_HB_DIR=str(tmp_path))
+    env.pop("AFSK_BENCH_LAUNCHER", None)
+    p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for ln in iter(p.stderr.readline, ""):                             # (heartbeats are silent at rank > 0)
+        if "READY" in ln:
+            break
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=30)
+    assert p.returncode == bench_mod().EXIT_RANK_FAILED
+    doc = _one_line(out)
+    assert doc["printed_by"] == "rank 1" and "SIGTERM" in doc["error"]
+    assert doc["heartbeats"]["0"] == {"phase": "shard built", "age_s": doc["heartbeats"]["0"]["age_s"],
+                                      "since_start_s": 1.0, "alive": False}
+    assert doc["phase"] == "shard built"                               # rank 0's last phase, from its heartbeat
+
+
+def test_failure_line_stays_under_the_cap():
+    import bench
+    hbs = {str(r): {"phase": "x" * 120, "age_s": 1.0, "since_start_s": 2.0, "alive": True} for r in range(8)}
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_n1.json")))
+    partial = bench.compact_line(full, "gpurun_out/bench_full_n1.json")
+    line = bench.failure_line(8, 20, 5, "e" * 2000, "p" * 500, hbs, partial)
+    assert len(json.dumps(line)) < bench.LINE_CAP and line["value"] == full["value"] and line["incomplete"] is True
+    line = bench.failure_line(8, 20, 5, "boom", "pg up", hbs, None)
+    assert len(json.dumps(line)) < bench.LINE_CAP and line["value"] is None
+    assert set(CONTRACT_KEYS) <= set(line)
+
+
+def test_thread_budget_is_divided_by_the_local_world(monkeypatch):
+    import bench
+    whole = bench.usable_cpus(local_world=1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert bench.usable_cpus() == max(1, whole // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert bench.usable_cpus() == whole
+
+
+def test_launcher_counts_gpus_without_torch():
+    """The launcher parent must not initialise HIP: devices are counted in sysfs (None / 0 without a KFD node)."""
+    import bench
+    n = bench.visible_gpus()
+    assert n is None or n >= 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def self_launch"):src.index("class Watchdog")]
+    assert "import torch" not in launcher and "torch.cuda" not in launcher
+
+
+def test_rank_side_without_a_gpu_prints_one_diagnostic_line():
+    """The product has no CPU fallback: the real rank code on a box without a HIP device ends in ONE line that says
+    so (value null, the phase it was in), exit code non-zero -- in-process at N = 1 and under torch.distributed.run."""
+    import torch
+    if torch.cuda.device_count() >= 1:
+        pytest.skip("a GPU is visible here")
+    bench_py = os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, bench_py, "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    doc = _one_line(p.stdout)
+    assert p.returncode == bench_mod().EXIT_RANK_FAILED
+    assert doc["value"] is None and "no HIP device" in doc["error"] and doc["phase"] == "checking for a HIP device"
+    assert doc["steps"] == 2 and doc["n_gpus"] == 1 and set(CONTRACT_KEYS) <= set(doc)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(bench_mod().free_port()),
+                        bench_py, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    doc = _one_line(p.stdout)                                          # rank 0 prints, rank 1 only exits
+    assert p.returncode != 0 and doc["printed_by"] == "rank 0" and doc["n_gpus"] == 2
+    assert "no HIP device" in doc["error"] and set(doc["heartbeats"]) == {"0", "1"}
 
 
 def test_bare_interpreter_refuses_more_gpus_than_visible():
@@ -86,7 +245,10 @@ def test_headline_workload_is_the_same_at_every_n():
     assert blocks[1]["workload"] == blocks[2]["workload"] == blocks[8]["workload"]
     assert blocks[8]["streams_total"] == 524288
     one, two = bench.plan(1), bench.plan(2)
-    assert one["subs"] == ["config2", "config3", "config4"] and one["next"] == list(bench.NEXT_ROWS) + ["rates_4096", "rates_65536"]
+    assert one["subs"] == ["config2", "config3", "config4"]
+    assert one["next"] == ["f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"] == list(bench.DEFAULT_RIDERS)
+    # the egress mirror and the 4096-stream table are measured on request only
+    assert bench.plan(1, "", "f5_wav_egress,rates_4096")["next"] == ["f5_wav_egress", "rates_4096"]
     assert len(bench.ALL_RATES) == 36 and set((300, 1200, 2400, 100, 160, 96, 24, 12000)) <= set(bench.ALL_RATES)
     assert two["subs"] == ["config2"] and two["next"] == []
     # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline

@@ -77,6 +77,14 @@ def _files(tmp_path):
     (tmp_path / "clip.wav").write_bytes(hdr(36 + 300, 768) + body)              # the RIFF form ends inside the data
     (tmp_path / "odd.wav").write_bytes(hdr(36 + 767, 767) + body[:767] + b"\x00")
     names += [str(tmp_path / "trunc.wav"), str(tmp_path / "clip.wav"), str(tmp_path / "odd.wav")]
+    # a canonical header whose RIFF size field puts a chunk header outside the form (streamed / truncated writers
+    # leave 0 there): the stdlib reader raises for these, so the one-preadv fast path must not report them OK
+    for rs in (0, 4, 20, 30, 35):
+        fn = tmp_path / f"riff{rs}.wav"
+        fn.write_bytes(hdr(rs, 768) + body)
+        names.append(str(fn))
+    (tmp_path / "riff36.wav").write_bytes(hdr(36, 768) + body)                  # form ends right behind the data header: 0 frames, readable
+    names.append(str(tmp_path / "riff36.wav"))
     junk = tmp_path / "junk.wav"
     junk.write_bytes(b"not a wav file at all" * 50)
     names += [str(junk), str(tmp_path / "missing.wav")]
@@ -276,3 +284,55 @@ def test_egress_writes_what_the_stdlib_writer_writes(stub, tmp_path):
     assert stub.afsk_wav_egress(arr, 0, None, None, None, None) == 0
     bad = offs.copy(); bad[3] = bad[2]                                         # overlapping streams
     assert stub.afsk_wav_egress(arr, n, dev.ctypes.data, p64(bad), p32(lens), p32(status)) == _native.E_INVALID_ARG
+
+
+def test_ingest_differential_fuzz_against_the_stdlib_reader(stub, tmp_path):
+    """The one-pass ingest (fast path and general walk alike) against `wave` on 1500 generated files: the random RIFF
+    files of the probe fuzz plus canonical 44-byte headers with hostile RIFF / data size fields (0, tiny, clipping,
+    overshooting).  A file the stdlib reader rejects is never delivered as OK; an OK file is delivered byte-exact."""
+    import struct
+    from tests.test_wav_probe_fuzz import _random_file
+    rng = np.random.default_rng(20261107)
+    names = []
+    for i in range(1500):
+        if i % 3 == 0:
+            nd = int(rng.choice([0, 2, 100, 768, 4096, 20000]))
+            body = bytes(rng.integers(0, 256, nd, dtype=np.uint8))
+            riff = int(rng.choice([0, 4, 12, 20, 30, 35, 36, 37, 36 + nd // 2, 36 + nd, 36 + nd + 1, 36 + nd + 9, 1 << 24]))
+            dsz = int(rng.choice([0, 1, nd // 2, nd, nd + 1, nd + 100, 0xFFFFFFFF]))
+            tag, ch, bits = int(rng.choice([1, 1, 1, 3])), int(rng.choice([1, 1, 2, 0])), int(rng.choice([16, 16, 8, 24, 0]))
+            blob = (b"RIFF" + struct.pack("<L", riff) + b"WAVEfmt " +
+                    struct.pack("<LHHLLHH", 16, tag, ch, 48000, 96000, ch * ((bits + 7) // 8) & 0xFFFF, bits) +
+                    b"data" + struct.pack("<L", dsz) + body)
+            if rng.random() < 0.1:
+                blob = blob[: int(rng.integers(0, len(blob) + 1))]
+        else:
+            blob = _random_file(rng)
+        fn = tmp_path / f"z{i:04d}.wav"
+        fn.write_bytes(blob)
+        names.append(str(fn))
+    n = len(names)
+    keep, arr = _c_paths(names)
+    sizes = np.zeros(n, np.int64)
+    assert stub.afsk_file_sizes(arr, n, p64(sizes)) == 0
+    slot = ((np.maximum(sizes, 0) // 2) + 7) & ~np.int64(7)
+    offs = np.zeros(n, np.int64)
+    offs[1:] = np.cumsum(slot[:-1])
+    total = int(offs[-1] + slot[-1]) + 8
+    dev = np.full(total, PATTERN, np.int16)
+    d_off, d_bytes, status = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+    assert stub.afsk_wav_ingest(arr, n, p64(offs), p64(slot), dev.ctypes.data, total, p64(d_off), p64(d_bytes), p32(status)) == 0
+    ok = rejected = declined = 0
+    for i, fn in enumerate(names):
+        want = _reference_bytes(fn)
+        got = dev[int(offs[i]): int(offs[i] + slot[i])].tobytes()
+        if status[i] == 0:
+            assert want is not None, (os.path.basename(fn), "ingest OK but the stdlib reader raises", open(fn, "rb").read(64).hex())
+            assert int(d_bytes[i]) & ~1 == len(want) and got[: len(want)] == want, os.path.basename(fn)
+            assert got[len(want):] == bytes(len(got) - len(want)), os.path.basename(fn)
+            ok += 1
+        else:
+            assert got == bytes(len(got)), os.path.basename(fn)       # zeroed slot for the caller's stdlib fallback
+            rejected += want is None
+            declined += want is not None
+    assert ok > 300 and rejected > 300 and declined <= ok // 8, (ok, rejected, declined)

@@ -195,6 +195,37 @@ def test_bench_two_rank_flow_on_one_gpu():
     assert d["gather_check"] == [True, True] and d["gather_check_on_every_rank"] is True
     assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
     assert d["config"]["streams_total"] == 1536 and d["gathers_in_timed_region"] == 3
+    # the same K-step regions without the exchange, next to the headline (gather cost separately)
+    assert d["value_no_gather"] > 0 and d["gather_ms"]["median"] > 0 and d["host_threads_per_rank"] >= 1
+    assert "pg up" in p.stderr and "first collective done: 2 ranks answered" in p.stderr and len(p.stderr) < 4096
+
+
+@pytest.mark.parametrize("fault,rc_name,needle", [("1:die:shard built", "EXIT_RANK_FAILED", "rank 1 -> exit code 7"),
+                                                  ("1:hang:timing without", "EXIT_DEADLINE", "deadline of")])
+def test_bench_failure_paths_end_in_one_diagnostic_line(fault, rc_name, needle):
+    """The un-losable line, rehearsed on the real rank code: rank 1 dies after building its shard / hangs before its
+    first timed region (fault injection), rank 0 waits in a collective that can never complete.  The launcher
+    terminates both, prints ONE line (value null, which rank, what every rank was doing) and exits non-zero."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--share-gpu0", "--workload", "config2", "--streams", "768", "--sub", "", "--steps", "9",
+                        "--warmup", "2", "--preroll-ms", "0", "--deadline-s", "75"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, AFSK_BENCH_FAULT=fault))
+    took = time.monotonic() - t0
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert p.returncode == getattr(bench, rc_name) and took < 200, (p.returncode, took, p.stderr[-1500:])
+    assert d["value"] is None and d["n_gpus"] == 2 and needle in d["error"], d
+    assert set(d["heartbeats"]) == {"0", "1"} and d["heartbeats"]["1"]["phase"].startswith(fault.split(":")[2])
+    assert d["metric"] == bench.METRIC and d["printed_by"] == "launcher"
 
 
 def _ragged_rank(rank, world, port, n_total, q):
@@ -296,7 +327,7 @@ def test_bench_three_rank_rehearsal_full_size_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["ranks_seen"] == 3
     assert d["gather_check"] == [True] * 3 and d["gather_check_on_every_rank"] is True
-    assert d["gather_ms"]["median"] > 0
+    assert d["gather_ms"]["median"] > 0 and d["value_no_gather"] > 0
     assert d["config"]["streams_per_gpu"] == 65536 and d["config"]["streams_total"] == 3 * 65536
     assert d["config"]["workload"].startswith("configs[4]")
     assert d["roundtrip_match_rate"] == 1.0 and d["all_timed_steps_identical"] is True
@@ -310,7 +341,7 @@ def test_bench_three_rank_rehearsal_full_size_on_one_gpu():
 
 def test_bench_default_line_at_n1_is_compact_and_complete():
     """The driver's own invocation shape (`python bench.py --gpus 1 ...`, every default rider: config2/3/4, f1/f2/f3,
-    the 36-rate tables) at reduced step counts: ONE line under 4 KB carrying the contract's keys, `roofline` and
+    the steady-state 36-rate table) at reduced step counts: ONE line under 4 KB carrying the contract's keys, `roofline` and
     `cpu_baseline`; the 30 KB full record in the file the line names.  (Round 3's line was 26 KB and the driver,
     which keeps ~8 KB of output, could parse nothing.)"""
     import json
@@ -335,11 +366,31 @@ def test_bench_default_line_at_n1_is_compact_and_complete():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["match_rate"] == 1.0 and d["roundtrip_match_rate"] == 1.0
     subs = d["sub_records"]
-    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress", "rates_4096",
-            "rates_65536"} <= set(subs)
-    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest", "f5_wav_egress"):
+    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"} == set(subs)
+    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest"):
         assert subs[name]["match_rate"] == 1.0, name
+    assert "error" not in json.dumps(subs) and "incomplete" not in d
     assert subs["config4"]["ber_equals_cpu"] is True
     full = json.load(open(os.path.join(root, d["full_record"])))
     assert full["value"] == d["value"] and len(full["sub_records"]["rates_65536"]["by_baud"]) == 36
-    assert full["sub_records"]["rates_4096"]["all_round_trips_exact"] and full["sub_records"]["rates_65536"]["all_round_trips_exact"]
+    assert full["sub_records"]["rates_65536"]["all_round_trips_exact"]
+
+
+def test_bench_on_request_riders_and_a_failing_rider():
+    """f5_wav_egress and rates_4096 are measured on request (--sub); and a rider that raises (here: an unwritable
+    scratch directory for the file rows) becomes {"error": ...} in the line while the headline keeps its numbers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "config2", "--steps", "6",
+            "--warmup", "2", "--preroll-ms", "0", "--no-cpu-baseline", "--wav-files", "64", "--rates-steps", "4"]
+    p = subprocess.run(base + ["--sub", "f5_wav_egress,rates_4096"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["sub_records"]["f5_wav_egress"]["match_rate"] == 1.0 and d["sub_records"]["rates_4096"]["all_round_trips_exact"]
+    p = subprocess.run(base + ["--sub", "f3_wav_ingest"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, AFSK_BENCH_TMPDIR="/proc/afsk_no_such_dir"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["value"] > 0 and d["roundtrip_match_rate"] == 1.0 and "error" in d["sub_records"]["f3_wav_ingest"], d

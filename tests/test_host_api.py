@@ -52,6 +52,58 @@ def test_constructor_errors_match_reference(golden):
             r.check_decodable(100)   # too short never raises (ref:323-325)
 
 
+def _outcome(fn):
+    try:
+        return fn()
+    except BaseException as e:  # noqa: BLE001
+        return f"raises {type(e).__name__}: {e}"
+
+
+def test_degenerate_constructor_arguments_match_reference(golden, tmp_path):
+    """Negative baud rates and negative training times CONSTRUCT in the reference (range(negative): empty tones,
+    zero training cycles: ref:71-76, 277, 438, 457); every outcome below was recorded from the reference itself."""
+    deg = golden["degenerate_api"]
+    afskmodem.LOG_LEVEL = 5
+    long_frames = afskmodem.Transmitter(1200).frames(b"Hi!")
+    for baud_s, e in deg["bauds"].items():
+        b = int(baud_s)
+        assert _outcome(lambda: afskmodem.Waveforms.getSpaceTone(b)) == e["space"], baud_s
+        assert _outcome(lambda: afskmodem.Waveforms.getMarkTone(b)) == e["mark"], baud_s
+        assert _outcome(lambda: afskmodem.Waveforms.getTrainingCycle(b)) == e["training"], baud_s
+        assert _outcome(lambda: "ok" if afskmodem.Receiver(b) else "ok") == e["receiver"], baud_s
+        assert _outcome(lambda: "ok" if afskmodem.Transmitter(b) else "ok") == e["transmitter"], baud_s
+        if e["transmitter"] == "ok":
+            t = afskmodem.Transmitter(b)
+            fr = t.frames(b"Hi!")
+            assert {"n_frames": len(fr), "frames_sha256": sha_i16(fr)} == e["frames"], baud_s
+            fn = str(tmp_path / f"neg{abs(b)}.wav")
+            t.save(b"Hi!", fn)
+            assert hashlib.sha256(open(fn, "rb").read()).hexdigest() == e["save"], baud_s
+            t.save_batch([b"Hi!"], [fn])                       # (bit_frames < 4: the per-file host path, no GPU needed)
+            assert hashlib.sha256(open(fn, "rb").read()).hexdigest() == e["save"], baud_s
+        if e["receiver"] == "ok":
+            r = afskmodem.Receiver(b)
+            for tag, frames in (("decode_4000", long_frames[:4000]), ("decode_4096", long_frames[:4096]),
+                                ("decode_full", long_frames), ("decode_empty", long_frames[:0])):
+                want = e[tag]
+                if want.startswith("raises"):
+                    # the sync search compares against an empty template: the reference's own exception
+                    assert _outcome(lambda: r.decode_frames(frames)) == want, (baud_s, tag)
+                else:
+                    assert want == "bits:"                     # too short: the early return (ref:323-325), no launch
+                    assert r.decode_frames(frames) == b"", (baud_s, tag)
+            fn = str(tmp_path / "in1200.wav")
+            afskmodem.Transmitter(1200).save(b"Hi!", fn)
+            assert _outcome(lambda: r.load(fn, False)) == e["load_1200_baud_file"], baud_s
+    for c in deg["training_time"]:
+        t = afskmodem.Transmitter(c["baud"], c["training_time"])
+        assert t.ts_cycles == c["ts_cycles"]                  # the attribute keeps the reference's (negative) value
+        fr = t.frames(b"Hi!")
+        assert (len(fr), sha_i16(fr)) == (c["n_frames"], c["frames_sha256"]), c
+        w = t.wav_samples(b"Hi!")
+        assert (len(w), sha_i16(w)) == (c["n_wav"], c["wav_sha256"]), c
+
+
 def test_primitives(golden):
     for p in golden["primitives"]:
         assert afskmodem.Waveforms.getDiff(p["a"], p["b"]) == p["diff"]
@@ -470,3 +522,45 @@ def test_device_entry_argument_checks_need_no_gpu():
     batch._same_device(a.device, stream_offset=a, stream_len=None)
     with pytest.raises(ValueError, match="share one device"):
         batch._same_device(a.device, stream_offset=torch.empty(4, device="meta"))
+
+
+def test_plan_cache_is_thread_safe_and_never_closes_a_plan_in_use(monkeypatch):
+    """demod_batch(entry='auto') builds rate-grouped plans behind the caller's back and keeps eight of them: look-up,
+    insert and eviction from several threads at once must neither raise nor free a plan somebody still holds --
+    an evicted plan is dropped from the cache and dies with its last reference (here: a fake plan that records it)."""
+    import threading
+    closed, live = [], []
+
+    class FakePlan:
+        def __init__(self, bit_frames, device=None):
+            self.bit_frames = np.ascontiguousarray(np.asarray(bit_frames, np.int32).reshape(-1))
+            self.closed = False
+            live.append(self)
+
+        def close(self):
+            self.closed = True
+            closed.append(self)
+
+    monkeypatch.setattr(batch, "GroupPlan", FakePlan)
+    monkeypatch.setattr(batch, "_PLAN_CACHE", {})
+    errors = []
+
+    def worker(t):
+        rng = np.random.default_rng(t)
+        try:
+            for _ in range(400):
+                k = int(rng.integers(0, 24))                      # 24 layouts > 8 cache slots: constant eviction
+                arr = np.full(16, 40, np.int32)
+                arr[k % 16] = 20 + 4 * (k // 16)
+                plan = batch._cached_plan(arr, 16, "cuda:0")
+                assert not plan.closed and np.array_equal(plan.bit_frames, arr)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert len(batch._PLAN_CACHE) <= batch._PLAN_CACHE_MAX and not closed      # the cache itself never closes a plan

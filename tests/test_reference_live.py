@@ -134,3 +134,35 @@ def test_decodes_match_the_live_reference(ref):
             assert O.load_frames(x, baud, amp_end) == want, (tag, baud, seed)
             rci = ref.Receiver(baud)._Receiver__recoverClockIndex([int(v) for v in x])
             assert O.recover_clock_index(x, baud) == rci == ci, (tag, baud, seed)
+
+
+def test_degenerate_constructor_arguments_match_the_live_reference(ref):
+    """Negative rates and negative training times, drawn fresh every run: construction, templates and the
+    Transmitter's frames of the host mirror against the imported reference (outcome by outcome: the same
+    value or the same exception text) -- the committed fixture holds a fixed list (`degenerate_api`)."""
+    seed = _seed()
+    rng = np.random.default_rng(seed)
+
+    def outcome(fn):
+        try:
+            return fn()
+        except BaseException as e:  # noqa: BLE001
+            return f"raises {type(e).__name__}: {e}"
+
+    divisors = [d for d in range(1, 48001) if 48000 % d == 0]
+    bauds = [-int(rng.choice(divisors)) for _ in range(12)] + [-int(rng.integers(1, 100000)) for _ in range(6)] + [0]
+    for baud in bauds:
+        for name in ("getSpaceTone", "getMarkTone", "getTrainingCycle"):
+            assert outcome(lambda: getattr(product.Waveforms, name)(baud)) == \
+                   outcome(lambda: getattr(ref.Waveforms, name)(baud)), (name, baud, seed)
+        assert outcome(lambda: bool(product.Receiver(baud))) == outcome(lambda: bool(ref.Receiver(baud))), (baud, seed)
+        want = outcome(lambda: ref.Transmitter(baud)._Transmitter__getFrames(b"xy"))
+        got = outcome(lambda: product.Transmitter(baud).frames(b"xy").tolist())
+        assert got == want, (baud, seed)
+    for _ in range(8):
+        baud = int(rng.choice([300, 1200, 2400, 6000]))
+        tt = -float(rng.random() * rng.choice([0.001, 1.0, 50.0]))
+        data = rng.integers(0, 256, 3, dtype=np.uint8).tobytes()
+        rt, pt = ref.Transmitter(baud, tt), product.Transmitter(baud, tt)
+        assert pt.ts_cycles == rt._Transmitter__ts_cycles, (baud, tt, seed)
+        assert pt.frames(data).tolist() == rt._Transmitter__getFrames(data), (baud, tt, seed)
