@@ -90,8 +90,17 @@ struct FastRing {
 
     // Requests complete in issue order, so chunk `need` has landed once at most as many requests as
     // were issued after it are outstanding; FIXED = that count without the warming requests.
+    // (r5: always the immediate.  The warming / probe requests sit between chunk 15 and chunk 16 in issue order, so
+    // while need < 16 this waits for up to warm_ops requests more than it has to -- requests that were issued
+    // one or two rounds earlier and have landed -- instead of running a scalar test and a switch in EVERY round:
+    // every instruction, scalar ones too, costs a wave four cycles of its issue slot.)
     template <int FIXED>
-    __device__ __forceinline__ void wait_fixed(int need) {
+    __device__ __forceinline__ void wait_fixed(int /*need*/) {
+        wait_vmcnt<FIXED>();
+    }
+    // the exact form, for the one wait per stream in front of phase A (two chunks more would delay its start)
+    template <int FIXED>
+    __device__ __forceinline__ void wait_exact(int need) {
         if (warm_ops != 0 && need < kRingChunks) wait_vmcnt_dyn(FIXED + warm_ops);
         else wait_vmcnt<FIXED>();
     }
@@ -107,6 +116,8 @@ struct FastRing {
                                    // holding chunks back (round loops with a fixed schedule switch to the
                                    // dynamic one), bits 3..: misses
     int hint_lim = 0x7fffffff;     // chunks at or above this index are not requested ahead of need
+    int eval_need = 0x7fffffff;    // the probes are evaluated in the first round whose last chunk is >= this (one
+                                   // compare per round: request_probes arms it with kRingChunks, eval_probes disarms it)
 
     __device__ __forceinline__ bool hint_armed() const { return (hint_state & 1) != 0; }
     __device__ __forceinline__ bool hint_holding() const { return (hint_state & 4) != 0; }
@@ -132,6 +143,7 @@ struct FastRing {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + kProbeOffset), 16, (int)(po - 16u), 0, 0, 0);
         warm_ops += 1;
         hint_state = 1;
+        eval_need = kRingChunks;
     }
     // chunk `need` has landed (dynamic form of wait_fixed: the number of requests behind it varies
     // once chunks are held back)
@@ -159,12 +171,46 @@ struct FastRing {
             next++;
         }
     }
+    // ---- rounds that are not whole chunks (wm_rounds / gp_rounds), the common case in two tests (r5) ----
+    // `pos` = first stream byte of the round, RB = bytes from there to the last byte it reads, inclusive.  While the
+    // refill runs at the watermark -- next == (pos >> 10) + 16: every chunk below the round's first byte has been
+    // requested again and nothing is held back -- at least 15 - CMAX requests were issued behind the chunk of the
+    // round's last byte (CMAX = the most chunk boundaries RB bytes can cross), so that immediate is a sufficient
+    // wait (one chunk more than necessary in the rounds that cross fewer).  Otherwise: the exact, dynamic form.
+    template <int AUX, int RB, bool HINTED>
+    __device__ __forceinline__ void wait_round(int pos) {
+        constexpr int CMAX = (RB + 1023) >> 10;
+        static_assert(CMAX < kRingChunks - 1, "round too large for the ring");
+        if (next == (pos >> 10) + kRingChunks) {
+            wait_vmcnt<kRingChunks - 1 - CMAX>();
+        } else {
+            const int need = (pos + RB - 1) >> 10;
+            if constexpr (HINTED) fetch_through<AUX>(need);
+            wait_landed(need);
+        }
+    }
+    // refill behind a round of RBYTES bytes: every chunk wholly below the next round's first byte.  At the
+    // watermark that is RBYTES >> 10 chunks or one more: straight-line requests instead of a loop.
+    template <int AUX, int RBYTES, bool HINTED>
+    __device__ __forceinline__ void refill_round(int pos) {
+        constexpr int CMIN = RBYTES >> 10;
+        const int lim = ((pos + RBYTES) >> 10) + kRingChunks;
+        if (next == (pos >> 10) + kRingChunks && (!HINTED || lim <= hint_lim)) {
+#pragma unroll
+            for (int j = 0; j < CMIN; j++) issue<AUX>(next + j);
+            next += CMIN;
+            if (next < lim) { issue<AUX>(next); next++; }
+        } else {
+            top_up<AUX, HINTED>(lim);
+        }
+    }
     // once a chunk >= 16 has landed the probes have too: hold back everything behind the round group
     // whose closing probe is the first quiet one after the last loud one (amp1 = the squelch threshold
     // per sample, 0 = nothing is ever quiet; base as given to request_probes; extra = bytes a round
     // reads past its end when re-aligning)
     __device__ __forceinline__ void eval_probes(int need, uint32_t amp1, int base, int extra) {
-        if ((hint_state & 2) || need < kRingChunks) return;
+        if (need < eval_need) return;
+        eval_need = 0x7fffffff;
         hint_state |= 2;
         wave_lds_sync();
         const int step = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset));
@@ -268,7 +314,7 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     const int lane = fr.lane;
     using std::integral_constant;
 
-    fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
+    fr.template wait_exact<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
     const int ll = lane < L::LANES ? lane : L::LANES - 1;    // idle lanes re-read the last window
     const uint8_t* src = fr.ring + (GC * 2) * ll;
@@ -354,7 +400,7 @@ __device__ __forceinline__ int recover_clock_index_lane_steps(FastRing& fr, uint
     const int lane = fr.lane;
     using std::integral_constant;
 
-    fr.template wait_fixed<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
+    fr.template wait_exact<PRE - 8>(7);                       // chunks 0..7 (samples 0..4095) have landed
     if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
     // total(0) = C + sum_j sigma_j x[j] over the 2*BF template samples: dword m = samples 2m, 2m + 1,
     // lanes stride through the BF dwords; sigma = -1 where the template is 32767 (per sample: with an odd
@@ -554,17 +600,78 @@ __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
     d.bytes_done = jnew;
 }
 
+// 64 coded symbols per flush: (avail - term_sym) / 14 - bytes_done >= 64 without the division (r5: every scalar
+// instruction of a round costs the wave four cycles of its issue slot, like a vector one)
+__device__ __forceinline__ bool rxd_flush_due(const RxDeferred& d, int avail) {
+    return d.st.phase == 1 && avail - d.st.term_sym >= 14 * (d.bytes_done + 64);
+}
+
 // one pass of PS symbols: terminator scan, lazy squelch amplitude, park the bits, maybe flush
 template <int PS, class AmpFn>
 __device__ __forceinline__ void rxd_pass(RxDeferred& d, uint64_t bmask, int nv, int k0, int lane,
                                          unsigned long long* words, uint8_t* out_row, int out_stride,
                                          AmpFn&& amp_ok_mask) {
-    const int start = rx_training(d.st, bmask, nv, k0);
+    int start = -1;
+    if (d.st.phase == 0) {
+        // A terminator (1,0,0,0: ref:386-390) needs zero decisions in a row, which the training tone -- alternating
+        // decisions -- does not have: when no position of a FULL pass holds a zero right behind a zero (the
+        // decision before the pass included) only the three-decision history moves on; everything else takes
+        // the complete scan of rx_training.
+        const uint64_t prev = (bmask << 1) | ((d.st.hist >> 2) & 1u);            // the decision before each one
+        constexpr uint64_t kAll = PS >= 64 ? ~0ull : ((1ull << (PS & 63)) - 1ull);
+        if (nv == PS && PS >= 3 && ((~(bmask | prev)) & kAll) == 0)
+            d.st.hist = (uint32_t)(bmask >> (PS - 3)) & 7u;
+        else
+            start = rx_training(d.st, bmask, nv, k0);
+    } else if (d.st.phase == 1) {
+        start = 0;
+    }
     if (start >= 0 && start < nv) rxd_stop(d, amp_ok_mask(), start, nv, k0);
     rxd_store<PS>(d, bmask, nv, k0, lane, words);
-    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
-        rxd_flush<PS>(d, k0 + nv, lane, words, out_row, out_stride);
+    if (rxd_flush_due(d, k0 + nv)) rxd_flush<PS>(d, k0 + nv, lane, words, out_row, out_stride);
 }
+
+// Lane p <- the wave-uniform 64-bit word B[p] (p < SPL), zero in every other lane: one v_writelane_b32 per half
+// instead of a v_mov + v_cndmask pair.  ONE asm statement for all of them, opened by `s_nop 1`: the words are
+// ballots, i.e. SGPRs (or VCC) written by VALU compares, and on gfx940 / gfx950 a VALU instruction that reads an
+// SGPR needs two wait states behind the VALU instruction that wrote it.  The compiler pads its own code for that
+// (its hazard recogniser) but cannot see into inline asm -- separate statements, scheduled right behind their
+// compares, read stale words (r5: every 2400-baud stream found a terminator that was not there).  The lane select
+// is an immediate, so the ISA's other hazard of this instruction (SGPR lane select written by VALU) cannot arise.
+#define AFSK_WL(p, lo, hi) "\n\tv_writelane_b32 %0, %" #lo ", " #p "\n\tv_writelane_b32 %1, %" #hi ", " #p
+template <int SPL>
+__device__ __forceinline__ void spread_words(const uint64_t (&B)[SPL], uint32_t& wlo, uint32_t& whi) {
+    uint32_t lo = 0, hi = 0;
+#define AFSK_S(p) "s"((uint32_t)B[p]), "s"((uint32_t)(B[p] >> 32))
+    if constexpr (SPL == 2) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1));
+    } else if constexpr (SPL == 3) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7)
+                     : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2));
+    } else if constexpr (SPL == 4) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9)
+                     : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3));
+    } else if constexpr (SPL == 5) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11)
+                     : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3), AFSK_S(4));
+    } else if constexpr (SPL == 10) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11)
+                     AFSK_WL(5, 12, 13) AFSK_WL(6, 14, 15) AFSK_WL(7, 16, 17) AFSK_WL(8, 18, 19) AFSK_WL(9, 20, 21)
+                     : "+v"(lo), "+v"(hi)
+                     : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3), AFSK_S(4), AFSK_S(5), AFSK_S(6), AFSK_S(7), AFSK_S(8), AFSK_S(9));
+    } else {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+        for (int p = 0; p < SPL; p++) {
+            lo = lane == p ? (uint32_t)B[p] : lo;              // v_cndmask with the scalar word as a source
+            hi = lane == p ? (uint32_t)(B[p] >> 32) : hi;
+        }
+    }
+#undef AFSK_S
+    wlo = lo;
+    whi = hi;
+}
+#undef AFSK_WL
 
 // One ROUND of SPL x 64 symbols in a single phase-C step (instead of SPL dependent scalar passes):
 // lane p < SPL takes the ballot word of symbols k0 + 64p .. k0 + 64p + 63 (v_cndmask), so the
@@ -579,14 +686,18 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
                                           int lane, unsigned long long* words, uint8_t* out_row,
                                           int out_stride, AmpFn&& amp_word) {
     static_assert(SPL >= 2 && SPL <= 16, "one DPP row");
-    uint32_t wlo = 0, whi = 0;
-#pragma unroll
-    for (int p = 0; p < SPL; p++) {
-        wlo = lane == p ? (uint32_t)B[p] : wlo;                // v_cndmask with the scalar word as a source
-        whi = lane == p ? (uint32_t)(B[p] >> 32) : whi;
+    // word p of the round goes to lane p: one v_writelane_b32 per half (r5; r4 moved every half through a
+    // v_mov + v_cndmask pair -- 4 * SPL instructions per round, as many as the decisions themselves at 12000 baud)
+    uint32_t wlo, whi;
+    spread_words<SPL>(B, wlo, whi);
+    // symbols of this lane's word that exist: all 64 in every round but the stream's last (wave-uniform test)
+    uint64_t valid;
+    if (K - k0 >= 64 * SPL) {
+        valid = lane < SPL ? ~0ull : 0ull;
+    } else {
+        const int rem = K - k0 - 64 * lane;
+        valid = (lane >= SPL || rem <= 0) ? 0ull : (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
     }
-    const int rem = K - k0 - 64 * lane;                        // symbols of this lane's word that exist
-    const uint64_t valid = (lane >= SPL || rem <= 0) ? 0ull : (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull));
     const uint64_t w = (((uint64_t)whi << 32) | wlo) & valid;
     if (lane < SPL) words[((k0 >> 6) + lane) & (kBitWords - 1)] = w;
     d.filled = k0 + 64 * SPL;
@@ -595,11 +706,17 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
     if (d.st.phase == 0) {
         uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(w >> 32), 0x111, 0xf, 0xf, true);   // row_shr:1
         if (lane == 0) phi = d.st.hist << 29;                  // decisions k0-3 .. k0-1
-        const uint64_t b3 = (w << 3) | (uint64_t)(phi >> 29);
-        const uint64_t b2 = (w << 2) | (uint64_t)(phi >> 30);
         const uint64_t b1 = (w << 1) | (uint64_t)(phi >> 31);
-        const uint64_t hit = b3 & ~b2 & ~b1 & ~w & valid;      // window == 1,0,0,0 (ref:386-390)
-        const uint64_t any = __ballot(hit != 0);
+        // no zero decision right behind a zero one anywhere in the round (the training tone alternates): no
+        // terminator -- one 64-bit shift and one ballot instead of three shifts and the scan
+        uint64_t any = __ballot((~(w | b1) & valid) != 0);
+        uint64_t hit = 0;
+        if (any) {
+            const uint64_t b3 = (w << 3) | (uint64_t)(phi >> 29);
+            const uint64_t b2 = (w << 2) | (uint64_t)(phi >> 30);
+            hit = b3 & ~b2 & ~b1 & ~w & valid;                 // window == 1,0,0,0 (ref:386-390)
+            any = __ballot(hit != 0);
+        }
         if (any) {
             const int p = __builtin_ctzll(any);
             const uint64_t hw = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hit >> 32), p) << 32) |
@@ -614,13 +731,11 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
         start = 0;
     }
     if (start >= 0 && start < nv) {                            // squelch stop (ref:372-376)
-        uint32_t alo = 0, ahi = 0;
+        uint64_t A[SPL];
 #pragma unroll
-        for (int p = 0; p < SPL; p++) {
-            const uint64_t a = amp_word(p);
-            alo = lane == p ? (uint32_t)a : alo;
-            ahi = lane == p ? (uint32_t)(a >> 32) : ahi;
-        }
+        for (int p = 0; p < SPL; p++) A[p] = amp_word(p);
+        uint32_t alo, ahi;
+        spread_words<SPL>(A, alo, ahi);
         const int rel = start - 64 * lane;                     // data starts at bit rel of this lane's word
         const uint64_t from = rel <= 0 ? ~0ull : (rel >= 64 ? 0ull : ~((1ull << rel) - 1ull));
         const uint64_t stop = ~(((uint64_t)ahi << 32) | alo) & valid & from;
@@ -633,8 +748,7 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
             d.st.phase = 2;
         }
     }
-    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
-        rxd_flush<64>(d, k0 + nv, lane, words, out_row, out_stride);
+    if (rxd_flush_due(d, k0 + nv)) rxd_flush<64>(d, k0 + nv, lane, words, out_row, out_stride);
 }
 
 // end of stream: K symbols were examined unless the squelch stopped earlier
@@ -951,22 +1065,33 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         }
         uint32_t x[SPL * NO];
         const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
+        // a round that does not cross the ring end (two of three) reads at constant offsets from ONE lane address
+        // (r5: the masked form costs three VALU instructions per read for the wrap that mostly does not happen)
+        const bool nowrap = ALIGNED && rb + 1024 * R <= kRingBytes;    // wave-uniform
+        auto read_piece = [&](const uint8_t* p, int piece, int j) {
+            if constexpr (RW == 16) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
+                x[NO * piece + 4 * j] = t4[0]; x[NO * piece + 4 * j + 1] = t4[1];
+                x[NO * piece + 4 * j + 2] = t4[2]; x[NO * piece + 4 * j + 3] = t4[3];
+            } else {
+                const u32x2 t2 = *reinterpret_cast<const u32x2*>(p);
+                x[NO * piece + 2 * j] = t2[0]; x[NO * piece + 2 * j + 1] = t2[1];
+            }
+        };
+        if (nowrap) {
+            const uint8_t* src = fr.ring + rb + PB * lane;
+#pragma unroll
+            for (int piece = 0; piece < SPL; piece++)
+#pragma unroll
+                for (int j = 0; j < NR_READS; j++) read_piece(src + 64 * PB * piece + RW * j, piece, j);
+            asm volatile("" ::: "memory");                             // (keeps the compiler from merging the two forms into selects)
+        } else {
 #pragma unroll
         for (int piece = 0; piece < SPL; piece++) {
             const int pb = rb + 64 * PB * piece + PB * lane;
             if constexpr (ALIGNED) {
 #pragma unroll
-                for (int j = 0; j < NR_READS; j++) {
-                    const uint8_t* p = fr.ring + ((pb + RW * j) & (kRingBytes - 1));
-                    if constexpr (RW == 16) {
-                        const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
-                        x[NO * piece + 4 * j] = t4[0]; x[NO * piece + 4 * j + 1] = t4[1];
-                        x[NO * piece + 4 * j + 2] = t4[2]; x[NO * piece + 4 * j + 3] = t4[3];
-                    } else {
-                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(p);
-                        x[NO * piece + 2 * j] = t2[0]; x[NO * piece + 2 * j + 1] = t2[1];
-                    }
-                }
+                for (int j = 0; j < NR_READS; j++) read_piece(fr.ring + ((pb + RW * j) & (kRingBytes - 1)), piece, j);
             } else {
                 const int ab = pb & ~(RW - 1);
                 uint32_t W[NO + DW];
@@ -1000,6 +1125,7 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 #pragma unroll
                 for (int d = 0; d < NO; d++) x[NO * piece + d] = y[d];
             }
+        }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill right away
         if (HINTED && fr.hint_takes_over(R)) {
@@ -1052,7 +1178,12 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             }
             const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
             mg[piece] = (int32_t)sd - (int32_t)md;
-            B[piece] = __ballot(md < sd);                                      // ref:348-351
+            if constexpr ((BF & (BF - 1)) == 0)
+                // floor(mark / BF) < floor(space / BF)  <=>  mark < (space with its low log2(BF) bits cleared): one
+                // v_and + v_cmp instead of two shifts + v_cmp (the quotients above are only formed for the margins)
+                B[piece] = __ballot(mark < (space & ~(uint32_t)(BF - 1)));     // ref:348-351
+            else
+                B[piece] = __ballot(md < sd);                                  // ref:348-351
         }
         if constexpr (BF != 4) {
             if (margins) {                 // soft output, ONE test per round (r4: it sat inside the slice loop)
@@ -1140,11 +1271,24 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     const int lane = fr.lane;
     const int part = lane & (LPS - 1);
     const int32_t mlim = K < mstride ? K : mstride;
+    // 128-byte pieces (bit_frames 128): sixteen lanes of a ds_read_b128 group, 128 bytes apart, would meet on two
+    // bank quads -- an 8-way conflict on every read (r5 PMC: 79 % of the LDS cycles of this kernel).  A lane piece
+    // is two quarters of four 16-byte chunks, and inside a quarter the order of the chunks does not matter (one
+    // template, one sum): read j takes chunk (j + r) & 3 of quarter (j >> 2) ^ sw, with r = lane bits 1-2 and
+    // sw = lane bit 3 -- the 16 lanes of a group then touch 16 different bank quads -- and the two quarter sums
+    // are exchanged in the lanes with sw set.
+    constexpr bool SWZ = ALIGNED && BF == 128;
+    int swz_off[SWZ ? 8 : 1];
+    const bool swz_sw = SWZ && ((lane >> 3) & 1);
+    if constexpr (SWZ) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            swz_off[j] = 16 * (((j & 3) + ((lane >> 1) & 3)) & 3) + 64 * ((j >> 2) ^ ((lane >> 3) & 1));
+    }
     int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
-        if constexpr (HINTED) fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);   // a held-back chunk
-        fr.wait_landed(last >> 10);                               // chunks through last >> 10 have landed
+        fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + EXTRA, HINTED>(pos);   // chunks through last >> 10 have landed
         if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0 & ~(RW - 1), EXTRA);
         const int rb = pos & (kRingBytes - 1);                    // wave-uniform
         if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
@@ -1157,7 +1301,10 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         uint32_t W[NW];
 #pragma unroll
         for (int j = 0; j < NW * 4 / RW; j++) {
-            if constexpr (RW == 16) {
+            if constexpr (SWZ) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4_a16*>(src + swz_off[j]);
+                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+            } else if constexpr (RW == 16) {
                 const u32x4 t4 = *reinterpret_cast<const u32x4_a16*>(src + 16 * j);
                 W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
             } else if constexpr (RW == 8) {
@@ -1184,7 +1331,7 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         // every chunk wholly below the next round's first byte is free
-        fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
+        fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
 
         const int k0 = r * SPP;
         uint32_t mark = 0, space = 0;
@@ -1214,6 +1361,11 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
             for (int d = 0; d < Q / 2; d++) ha = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, ha);
 #pragma unroll
             for (int d = Q / 2; d < Q; d++) hb = __builtin_amdgcn_sad_u16(limit_pair_biased(x[d]), 0xFFFFFFFFu, hb);
+            if constexpr (SWZ) {               // lanes that read their second quarter first
+                const uint32_t t = ha;
+                ha = swz_sw ? hb : ha;
+                hb = swz_sw ? t : hb;
+            }
             mark = ha + (FULL * Q - hb);
             space = part == 0 ? ha + hb : 2u * FULL * Q - ha - hb;
         } else {
@@ -1361,8 +1513,7 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
     int pos = byte0;                                              // stream byte of the round's first sample
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + 3;                        // tail slot B of the last lane reaches one dword further
-        if constexpr (HINTED) fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
-        fr.wait_landed(last >> 10);
+        fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + 4, HINTED>(pos);
         if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0, 4);
         const int rb = pos & (kRingBytes - 1);
         if (rb + RBYTES + 4 > kRingBytes) {                       // a piece runs past the ring end: refresh the mirror
@@ -1408,7 +1559,7 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
             for (int d = 0; d < NB + 2; d++) x[d] = __builtin_amdgcn_alignbyte(W[d + 1], W[d], 2);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
-        fr.template top_up<(FLAGS & 4) ? 0 : 2, HINTED>(((pos + RBYTES) >> 10) + kRingChunks);
+        fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
 
         uint32_t h = 0;
 #pragma unroll
@@ -1497,8 +1648,7 @@ __device__ __forceinline__ void rxd_pass_rt(RxDeferred& d, uint64_t bmask, int n
         if (lane == 0) words[(k0 >> 6) & (kBitWords - 1)] = d.cur;
         d.cur = 0;
     }
-    if (d.st.phase == 1 && (k0 + nv - d.st.term_sym) / 14 - d.bytes_done >= 64)
-        rxd_flush<32>(d, k0 + nv, lane, words, out_row, out_stride);
+    if (rxd_flush_due(d, k0 + nv)) rxd_flush<32>(d, k0 + nv, lane, words, out_row, out_stride);
 }
 
 // ONE sweep over the offsets: every lane keeps the first offset of its own minimal truncated mean --
@@ -1512,7 +1662,7 @@ __device__ __forceinline__ int recover_clock_index_rt(FastRing& fr, int bf) {
     constexpr int GC = 24, STEP = 64 * GC;
     const int lane = fr.lane;
     const int N = 2 * bf, q = bf >> 2, h = bf >> 1, NOFF = kSync - N;
-    fr.template wait_fixed<kRingChunks - 8>(7);                 // chunks 0..7 (samples 0..4095) have landed
+    fr.template wait_exact<kRingChunks - 8>(7);                 // chunks 0..7 (samples 0..4095) have landed
     // total(0) = 65535 * bf + sum_j sigma_j x[j] over the 2*bf template samples (ref:80-91): dword m =
     // samples 2m, 2m + 1, lanes stride through the bf dwords
     uint32_t base;
@@ -1720,7 +1870,7 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
         fr.warm_ops = kWarmOps;
     }
     int ci = 0;
-    if constexpr (FLAGS & 1) fr.template wait_fixed<kRingChunks - 8>(7);
+    if constexpr (FLAGS & 1) fr.template wait_exact<kRingChunks - 8>(7);
     else ci = recover_clock_index_rt(fr, bf);
     ci_out = ci;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1781,7 +1931,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
 
     int ci = 0;
     if constexpr (FLAGS & 1) {
-        fr.template wait_fixed<PRE - 8>(7);
+        fr.template wait_exact<PRE - 8>(7);
     } else {
         // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
         // not: 72 + 320 samples), sub-windows in steps otherwise

@@ -6,7 +6,14 @@ set -euo pipefail
 cd "$(dirname "$0")"
 ARCH=${AFSK_ARCH:-gfx950}
 JOBS=${AFSK_BUILD_JOBS:-$(nproc)}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
+# -structurizecfg-skip-uniform-regions (r5): the AMDGPU backend structurizes wave-UNIFORM branches too by default
+# (flag registers, s_mov_b64 / s_andn2_b64 / extra s_cbranch per if), and these kernels are full of them -- one wave
+# = one stream, the whole receiver state machine is scalar.  A wave issues one instruction every four cycles
+# whatever its kind, so the scalar bookkeeping costs as much as the vector arithmetic: leaving uniform regions
+# as plain branches removes ~10 % of the static scalar instructions and 2 - 6 % of the kernel time
+# (profiles/r5_exp4_lib_ab.txt).  The flag is an LLVM-internal one: the bit-exact GPU suite and tools/fuzz_gpu.py
+# are what vouch for the code it produces.
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function -mllvm -structurizecfg-skip-uniform-regions"
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 # bit_frames values with a compile-time geometry = AFSK_FAST_BF_LIST + AFSK_GP_BF_LIST in afsk_demod_impl.h; 0 = run-time geometry

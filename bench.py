@@ -132,7 +132,8 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     d = os.path.join(ROOT, "afskmodem_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".h", ".hip")) and (fn.startswith("afsk_demod") or fn == "afsk_kernels.h"):
+        # (build.sh: the compiler flags are part of what a kernel is -- r5 added an -mllvm option worth 2 - 6 %)
+        if (fn.endswith((".h", ".hip")) and (fn.startswith("afsk_demod") or fn == "afsk_kernels.h")) or fn == "build.sh":
             h.update(fn.encode())
             h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]

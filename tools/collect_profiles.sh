@@ -7,9 +7,22 @@ cd "$(dirname "$0")/.."
 T=${1:-r3}; shift || true
 WL=${*:-config5 config2 config3 custom100 custom150 custom200}
 for w in $WL; do
-  [ -f gpurun_out/prof_summary_$w.json ] && cp gpurun_out/prof_summary_$w.json profiles/${T}_${w}_summary.json
-  f=$(ls gpurun_out/prof_trace_$w/*/*kernel_stats.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && cp "$f" profiles/${T}_${w}_kernel_stats.csv
+  # ONE rocprofv3 run per summary: the committed CSV is the very file the summary was computed from (its
+  # `kernel_stats_file`; gpurun_out/ accumulates the directories of earlier visits, so never "the first CSV
+  # found"), and the committed summary names the committed copy and its sha256
+  [ -f gpurun_out/prof_summary_$w.json ] && python - "$T" "$w" <<'PY'
+import hashlib, json, os, shutil, sys
+T, w = sys.argv[1:3]
+d = json.load(open(f"gpurun_out/prof_summary_{w}.json"))
+src = d.get("kernel_stats_file")
+if src and os.path.exists(src):
+    dst = f"profiles/{T}_{w}_kernel_stats.csv"
+    shutil.copyfile(src, dst)
+    d["kernel_stats_file_on_the_gpu_box"] = src
+    d["kernel_stats_file"] = dst
+    d["kernel_stats_sha256"] = hashlib.sha256(open(dst, "rb").read()).hexdigest()
+json.dump(d, open(f"profiles/{T}_{w}_summary.json", "w"), indent=1)
+PY
   [ -s gpurun_out/timeline_$w.txt ] && cp gpurun_out/timeline_$w.txt profiles/${T}_${w}_timeline.txt
   [ -s gpurun_out/prof_bench_$w.json ] && cp gpurun_out/prof_bench_$w.json profiles/${T}_bench_under_rocprof_${w}.json
 done

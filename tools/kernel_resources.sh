@@ -2,7 +2,7 @@
 # hipcc's own resource remark (-Rpass-analysis=kernel-resource-usage) for every shipped demod kernel, one
 # line each (cross-compiles gfx950 without a GPU).   bash tools/kernel_resources.sh > profiles/rN_kernel_resources.txt
 cd "$(dirname "$0")/../afskmodem_amd/csrc"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Rpass-analysis=kernel-resource-usage -c -o /dev/null"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -mllvm -structurizecfg-skip-uniform-regions -Rpass-analysis=kernel-resource-usage -c -o /dev/null"
 UNIFORM_BF=$(sed -n 's/^#define AFSK_\(FAST\|GP\)_BF_LIST(X)//p' afsk_demod_impl.h | tr -d 'X()' | tr '\n' ' ')
 WANT=$(sed -n 's/^static_assert(kUniformBfCount == \([0-9]*\),.*/\1/p' afsk_demod_impl.h)
 [ "$(echo $UNIFORM_BF | wc -w)" -eq "${WANT:-0}" ] || { echo "kernel_resources.sh: bit_frames lists do not match kUniformBfCount" >&2; exit 1; }

@@ -11,6 +11,6 @@ for spec in "$@"; do
   name=$w; [ -n "$lib" ] && name="${w}_$(basename $lib .so)" && export AFSK_AMD_LIB=$R/$lib || unset AFSK_AMD_LIB
   rm -rf gpurun_out/pmc_sq_$name
   ( cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_sq_$name -- python3 $R/bench.py $wl ${STREAMS:+--streams $STREAMS} --sub "" --steps 6 --warmup 2 --preroll-ms 0 --min-region-ms 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-80 )
-  python tools/summarize_pmc.py gpurun_out/pmc_sq_$name > gpurun_out/${T}_pmc_sq_$name.json
+  python tools/summarize_pmc.py "gpurun_out/pmc_sq_$name" > gpurun_out/${T}_pmc_sq_$name.json
   python -c "import json; d=json.load(open('gpurun_out/${T}_pmc_sq_$name.json')); print('$name', d.get('share_of_wave_cycles'), d.get('share_of_lds_active_cycles'))"
 done

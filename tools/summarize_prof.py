@@ -89,6 +89,7 @@ def compiler_resources(kernel_names):
             jobs.add(("afsk_demod_big.hip" if re.search(r"true\s*>", kn) else "afsk_demod_small.hip", ""))
     for src, define in sorted(jobs):
         cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+               "-mllvm", "-structurizecfg-skip-uniform-regions",       # as afskmodem_amd/csrc/build.sh
                "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + ([define] if define else [])
         try:
             txt = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True, timeout=600).stderr
