@@ -21,7 +21,9 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t stream) {
     const int blocks = (a.n_streams + kWavesPerBlock - 1) / kWavesPerBlock;
     // launches of kHintMinStreams or more run the kernel with the large-launch measures (L2 warming
     // from kWarmMinStreams, tail hint); smaller ones a kernel compiled without them
-    return a.n_streams >= kHintMinStreams ? launch_demod_big(a, blocks, stream) : launch_demod_small(a, blocks, stream);
+    // (a rate-sorted stream list -- the grouped dispatch -- takes them from kHintMinStreamsGrouped on)
+    const int big_from = a.stream_index ? kHintMinStreamsGrouped : kHintMinStreams;
+    return a.n_streams >= big_from ? launch_demod_big(a, blocks, stream) : launch_demod_small(a, blocks, stream);
 }
 
 hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream) {

@@ -73,6 +73,8 @@ constexpr int kWarmMinStreams = 8192;
 // with no loud probe at all still decodes, one demand fetch later.
 constexpr int kProbes = 64;               // one per lane; probes beyond the stream end cost nothing (range-checked)
 constexpr int kHintMinStreams = 6144;     // mixed-baud kernel: -2.6 % at 6144 streams, -0.7 ... +1.3 % at 4096 and below
+constexpr int kHintMinStreamsGrouped = 4096;   // the same kernel walking a rate-SORTED stream list (grouped dispatch): the
+                                               // +1.3 % at 4096 was measured in stream order (r5)
 // uniform kernels of bit_frames 4 / 8 (large-launch form, hint and warming alike): 12000 baud gains from 8192
 // streams on (0.65 -> 0.68; 16384: 0.65 -> 0.71; 32768: 0.72 -> 0.77), 6000 baud loses 2 % at 8192 / 12288 and gains
 // from 16384 on (0.69 -> 0.71; 32768: 0.69 -> 0.76) -- profiles/r4_exp4_hint_short.txt
@@ -654,6 +656,13 @@ __device__ __forceinline__ void spread_words(const uint64_t (&B)[SPL], uint32_t&
     } else if constexpr (SPL == 5) {
         asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11)
                      : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3), AFSK_S(4));
+    } else if constexpr (SPL == 6) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11) AFSK_WL(5, 12, 13)
+                     : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3), AFSK_S(4), AFSK_S(5));
+    } else if constexpr (SPL == 8) {
+        asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11) AFSK_WL(5, 12, 13)
+                     AFSK_WL(6, 14, 15) AFSK_WL(7, 16, 17)
+                     : "+v"(lo), "+v"(hi) : AFSK_S(0), AFSK_S(1), AFSK_S(2), AFSK_S(3), AFSK_S(4), AFSK_S(5), AFSK_S(6), AFSK_S(7));
     } else if constexpr (SPL == 10) {
         asm volatile("s_nop 1" AFSK_WL(0, 2, 3) AFSK_WL(1, 4, 5) AFSK_WL(2, 6, 7) AFSK_WL(3, 8, 9) AFSK_WL(4, 10, 11)
                      AFSK_WL(5, 12, 13) AFSK_WL(6, 14, 15) AFSK_WL(7, 16, 17) AFSK_WL(8, 18, 19) AFSK_WL(9, 20, 21)
@@ -1030,7 +1039,24 @@ template <int BF>
 struct MultiGeom {
     static constexpr bool valid = BF == 4 || BF == 8 || BF == 12 || BF == 16 || BF == 24 || BF == 32 ||
                                   BF == 48 || BF == 64;
-    static constexpr int R = BF == 4 || BF == 8 ? 5 : (BF == 32 ? 4 : (BF == 64 ? 8 : 6));   // chunks per round
+    // chunks per round (overridable per value for A/B builds: -DAFSK_R16=8 ...)
+#ifndef AFSK_R4
+#define AFSK_R4 5
+#endif
+#ifndef AFSK_R8
+#define AFSK_R8 5
+#endif
+#ifndef AFSK_R12
+#define AFSK_R12 6
+#endif
+#ifndef AFSK_R16
+#define AFSK_R16 6
+#endif
+#ifndef AFSK_R24
+#define AFSK_R24 6
+#endif
+    static constexpr int R = BF == 4 ? AFSK_R4 : (BF == 8 ? AFSK_R8 : (BF == 12 ? AFSK_R12 : (BF == 16 ? AFSK_R16 : (BF == 24 ? AFSK_R24 :
+                             (BF == 32 ? 4 : (BF == 64 ? 8 : 6))))));
     static constexpr int SPL = 8 * R / BF;                     // symbols per lane per round
     static constexpr int PB = 2 * BF;                          // bytes per symbol
     static constexpr int RW = BF % 8 == 0 ? 16 : 8;            // bytes per LDS read
@@ -1127,20 +1153,12 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             }
         }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill right away
-        if (HINTED && fr.hint_takes_over(R)) {
-            fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 1024 * R * (r + 1)) >> 10) + kRingChunks);
-        } else {
-#pragma unroll
-            for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
-            fr.next += R;
-        }
-
         const int k0 = r * SPR;
         uint64_t B[SPL];
         int32_t mg[SPL];                                                       // space_diff - mark_diff per slice (soft output)
-#pragma unroll
-        for (int piece = 0; piece < SPL; piece++) {
+        uint32_t l12[BF == 4 ? SPL : 1];                                       // bit_frames 4: the limited (sample 1, sample 2) pairs
+        auto decide = [&](auto pc) {
+            constexpr int piece = decltype(pc)::value;
             if constexpr (BF == 4) {
                 // One sample per quarter.  With the limited samples L0..L3 (biased levels 0 / 0x8000 / 0xFFFF)
                 // mark = (65535 - L0) + L1 + (65535 - L2) + L3 and space = (65535 - L0) + (65535 - L1) + L2 + L3
@@ -1149,41 +1167,68 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
                 // hide -- the decision int(mark / 4) < int(space / 4) IS L1 < L2 (exhaustive check:
                 // tests/test_kernel_math.py).  The two quotients themselves are only needed for the margins.
                 // Only samples 1 and 2 decide: one dword holding both goes through ONE limiter.  (The margins,
-                // which need all four samples, are formed after the loop.)
-                const uint32_t y = __builtin_amdgcn_alignbit(x[NO * piece + 1], x[NO * piece], 16);   // (sample 1, sample 2)
-                const uint32_t l12 = limit_pair_biased(y);
-                B[piece] = __ballot((l12 & 0xFFFFu) < (l12 >> 16));            // ref:348-351
-                continue;
-            }
-            uint32_t mark = 0, space = 0;
-            if constexpr (BF % 8 == 0) {
-                // quarters are whole dwords: SAD against "hi" per quarter gives both correlators
-                uint32_t hq[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int d = 0; d < NO; d++)
-                    hq[d / (Q / 2)] = __builtin_amdgcn_sad_u16(limit_pair_biased(x[NO * piece + d]), 0xFFFFFFFFu,
-                                                              hq[d / (Q / 2)]);
-                const uint32_t u = 2u * FULL * Q + hq[0] - hq[3], dd = hq[2] - hq[1];   // (modulo 2^32, like the sums)
-                mark = u + dd;
-                space = u - dd;
+                // which need all four samples, are formed after the loop; the ten compares follow it too.)
+                l12[piece] = limit_pair_biased(__builtin_amdgcn_alignbit(x[NO * piece + 1], x[NO * piece], 16));   // (sample 1, sample 2)
             } else {
+                uint32_t mark = 0, space = 0;
+                if constexpr (BF % 8 == 0) {
+                    // quarters are whole dwords: SAD against "hi" per quarter gives both correlators
+                    uint32_t hq[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int d = 0; d < NO; d++) {
-                    const uint32_t lim = limit_pair_biased(x[NO * piece + d]);
-                    const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
-                    const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
-                    mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
-                    space = __builtin_amdgcn_sad_u16(lim, ts, space);
+                    for (int d = 0; d < NO; d++)
+                        hq[d / (Q / 2)] = __builtin_amdgcn_sad_u16(limit_pair_biased(x[NO * piece + d]), 0xFFFFFFFFu,
+                                                                  hq[d / (Q / 2)]);
+                    const uint32_t u = 2u * FULL * Q + hq[0] - hq[3], dd = hq[2] - hq[1];   // (modulo 2^32, like the sums)
+                    mark = u + dd;
+                    space = u - dd;
+                } else {
+#pragma unroll
+                    for (int d = 0; d < NO; d++) {
+                        const uint32_t lim = limit_pair_biased(x[NO * piece + d]);
+                        const uint32_t tm = mark_half(2 * d, Q) | (mark_half(2 * d + 1, Q) << 16);
+                        const uint32_t ts = space_half(2 * d, H) | (space_half(2 * d + 1, H) << 16);
+                        mark = __builtin_amdgcn_sad_u16(lim, tm, mark);
+                        space = __builtin_amdgcn_sad_u16(lim, ts, space);
+                    }
                 }
+                const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
+                mg[piece] = (int32_t)sd - (int32_t)md;
+                if constexpr ((BF & (BF - 1)) == 0)
+                    // floor(mark / BF) < floor(space / BF)  <=>  mark < (space with its low log2(BF) bits cleared): one
+                    // v_and + v_cmp instead of two shifts + v_cmp (the quotients above are only formed for the margins)
+                    B[piece] = __ballot(mark < (space & ~(uint32_t)(BF - 1)));     // ref:348-351
+                else
+                    B[piece] = __ballot(md < sd);                                  // ref:348-351
             }
-            const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
-            mg[piece] = (int32_t)sd - (int32_t)md;
-            if constexpr ((BF & (BF - 1)) == 0)
-                // floor(mark / BF) < floor(space / BF)  <=>  mark < (space with its low log2(BF) bits cleared): one
-                // v_and + v_cmp instead of two shifts + v_cmp (the quotients above are only formed for the margins)
-                B[piece] = __ballot(mark < (space & ~(uint32_t)(BF - 1)));     // ref:348-351
-            else
-                B[piece] = __ballot(md < sd);                                  // ref:348-351
+        };
+        // The decisions of the first EARLY slices are formed while the reads of the later ones are still in flight
+        // (ds_reads return in order; the compiler places the partial waits); then, with every value in registers,
+        // the consumed chunks are requested again and the rest follows.  EARLY = 0: refill first, as until r5.
+#ifndef AFSK_MULTI_EARLY
+#define AFSK_MULTI_EARLY 0
+#endif
+        constexpr int EARLY = (AFSK_MULTI_EARLY) < 0 ? SPL / 2 : ((AFSK_MULTI_EARLY) < SPL ? (AFSK_MULTI_EARLY) : SPL - 1);
+        static_for<0, EARLY>(decide);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill
+        if (HINTED && fr.hint_takes_over(R)) {
+            fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 1024 * R * (r + 1)) >> 10) + kRingChunks);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+            fr.next += R;
+        }
+        static_for<EARLY, SPL>(decide);
+        if constexpr (BF == 4) {
+            static_assert(BF != 4 || SPL == 10, "ten slices per round");
+            // L1 < L2 (ref:348-351) as ONE 16-bit compare of the two halves of a register (SDWA operand selects): the
+            // compiler forms the same test from a mask, a shift and a 32-bit compare.  One asm statement, closed by
+            // s_nop 1: the ballots are SGPRs written by VALU, and whatever VALU instruction reads them next (the
+            // spreading of the words over the lanes) must be two wait states behind (see spread_words).
+#define AFSK_C(i) "v_cmp_lt_u16_sdwa %" #i ", %1" #i ", %1" #i " src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+            asm volatile(AFSK_C(0) AFSK_C(1) AFSK_C(2) AFSK_C(3) AFSK_C(4) AFSK_C(5) AFSK_C(6) AFSK_C(7) AFSK_C(8) AFSK_C(9) "s_nop 1"
+                         : "=s"(B[0]), "=s"(B[1]), "=s"(B[2]), "=s"(B[3]), "=s"(B[4]), "=s"(B[5]), "=s"(B[6]), "=s"(B[7]), "=s"(B[8]), "=s"(B[9])
+                         : "v"(l12[0]), "v"(l12[1]), "v"(l12[2]), "v"(l12[3]), "v"(l12[4]), "v"(l12[5]), "v"(l12[6]), "v"(l12[7]), "v"(l12[8]), "v"(l12[9]));
+#undef AFSK_C
         }
         if constexpr (BF != 4) {
             if (margins) {                 // soft output, ONE test per round (r4: it sat inside the slice loop)

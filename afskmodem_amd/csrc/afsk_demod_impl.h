@@ -263,7 +263,7 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     int ci = 0;
     unsigned long long* stamps = (FLAGS & 64) ? a.debug_stamps + 4 * s : nullptr;
     const bool warm = a.n_streams >= kWarmMinStreams;          // wave-uniform (afsk_demod_fast.h)
-    const bool hint = a.n_streams >= kHintMinStreams;
+    const bool hint = a.n_streams >= (a.stream_index ? kHintMinStreamsGrouped : kHintMinStreams);
     switch (bf) {
 #define AFSK_X(B) case B: demod_stream_fast<B, FLAGS, BIG>(xs, len, a.amp_end, lds, lane, st, out_row, a.out_stride, ci, n_sym, stamps, margins, a.margin_stride, warm, hint); break;
         AFSK_FAST_BF_LIST(AFSK_X)

@@ -1581,6 +1581,8 @@ def main() -> None:
                     help="N > 1: skip the extra K-step regions without the gather (value_no_gather)")
     args = ap.parse_args()
 
+    # dmabuf IPC for RCCL on this pool (exported on the boxes already; set before anything initialises HIP)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     global RATE_ORDER
     RATE_ORDER = args.rate_order
     if args.bauds:
