@@ -3,7 +3,7 @@
 //   20 / 40 / 80 / 160   (2400 / 1200 / 600 / 300 baud)        fast_rounds: 5 KiB rounds, 80-byte lane pieces
 //   240 / 320 / 480      (200 / 150 / 100 baud: below the documented range, but on the list of rates the
 //                         reference's code round-trips)         wm_rounds with 4 / 8 lanes per symbol
-//   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks, several
+//   4 / 8 / 12 / 16 / 24 / 32 / 48 / 64  (12000 ... 750 baud)  multi_rounds: rounds of whole chunks (5 / 5 / 6 / 8 / 6 / 4 / 6 / 8), several
 //                                                              symbols per lane
 //   60 / 96 / 100 / 120  (800 / 500 / 480 / 400 baud)          wm_rounds: rounds of any size, watermark refill
 // and every other valid bit_frames -- every multiple of 4 below 2048 that is not listed above: 28, 36,
@@ -82,6 +82,31 @@ constexpr int kHintMinStreamsShort4 = 8192;
 constexpr int kHintMinStreamsShort8 = 16384;
 constexpr int kHintMinStreamsUniform = 4096;   // uniform kernels (no scalar-register pressure): -0.8 ... -1.6 % at 4096 streams and 1.02 x
                                                // instead of 1.11 x the algorithmic bytes fetched; neutral at 2048
+
+// Squelch amplitude (ref:94-98, ref:375) without a bias instruction per dword (r5).  v_sad_u16 of the RAW packed
+// pair against 0x8000 per half gives, per sample, 32768 - |x|: a non-negative sample x reads as x (32768 - x), a
+// negative one as 65536 + x (minus 32768: 32768 - |x|), and -32768 gives 0 = 32768 - abs(-32768) like the
+// reference's Python abs.  So the "quiet sum" q of n samples is 32768 n - sum|x|, and
+//     sum|x| >= thr   <=>   q <= 32768 n - thr      (signed: thr may exceed 32768 n, then nothing is ever loud).
+// (r1-r4 formed |x| itself: v_xor with 0x80008000, then the same v_sad_u16 -- twice the instructions.)
+__device__ __forceinline__ uint32_t quiet_sad(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u16(x, kBias, acc); }
+__device__ __forceinline__ bool loud_enough(uint32_t quiet, uint32_t n_samples, uint32_t amp_thr) {
+    return (int32_t)quiet <= (int32_t)(32768u * n_samples) - (int32_t)amp_thr;
+}
+
+// Tail hint, second level (r5): with round-spaced probes alone a wave fetches up to one round past the end of the signal
+// -- half a round on average, 1.07 x the algorithmic bytes at 4000 baud, 6 KiB rounds (PMC).  Once the first level has
+// found the probe interval in which the signal ends, EIGHT more probes inside that interval (an eighth of it apart:
+// 0.6 - 1 KiB) narrow the limit down to a chunk; the round that then reaches past the limit is decoded from what has
+// been requested first (FastRing::holding_wait).  -1.6 ... -4.9 % where the one-level hint happened to waste most
+// (2000 / 1000 / 800 / 500 / 400 / 375 / 96 baud), neutral where the bench's payload sizes end near a round boundary
+// anyway (1200 / 2400 / 300 baud ...: profiles/r5_exp16_two_level_hint.txt, r5_exp17_*).  Measured alternative
+// (r5_exp14/15): 64 probes 1.5 KiB apart from the start cost 47 more requests and 2 - 3 KB of traffic per stream --
+// +2 ... 4 % for 5 KiB rounds, a wash for 6 KiB ones.  AFSK_REFINE_FROM: smallest round that takes the second level.
+#ifndef AFSK_REFINE_FROM
+#define AFSK_REFINE_FROM 3072
+#endif
+__host__ __device__ constexpr bool fine_probes(int round_bytes) { return round_bytes >= (AFSK_REFINE_FROM); }
 
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
@@ -164,6 +189,34 @@ struct FastRing {
             next++;
         }
     }
+    // Holding mode, top of a round that reads stream bytes up to `last` (inclusive) and starts at symbol k0 (symbol 0 at
+    // byte `base`, sym_bytes each; K symbols in the stream).  Returns how many symbols the round may use:
+    //   K       everything it reads has landed -- requested earlier, or (nothing of the round available: the r4
+    //           behaviour) fetched through now, or lying past the stream's last symbol;
+    //   < K     PARTIAL: the round reaches past what has been requested.  It is decoded from the symbols that lie wholly
+    //           below the requested bytes first: the squelch stop is almost always among them (that is what the probes
+    //           said), and then nothing more is ever fetched.  If it is not, the caller restores its state, fetches the
+    //           rest (fetch_through: a miss) and runs the round again -- results cannot depend on the hint.
+    template <int AUX>
+    __device__ __forceinline__ int32_t holding_wait(int last, int32_t K, int32_t k0, int base, int sym_bytes, bool& partial) {
+        const int need = last >> 10;
+        partial = false;
+        if (next <= need) {
+            const int32_t kp = (int32_t)(((uint32_t)next * 1024u - (uint32_t)base) / (uint32_t)sym_bytes);
+            if (kp >= K) {                                   // only bytes behind the last symbol are missing
+                wait_landed(next - 1);
+                return K;
+            }
+            if (kp > k0) {
+                partial = true;
+                wait_landed(next - 1);
+                return kp;
+            }
+            fetch_through<AUX>(need);
+        }
+        wait_landed(need);
+        return K;
+    }
     // request every chunk below lim (that the hint allows)
     template <int AUX, bool HINTED = true>
     __device__ __forceinline__ void top_up(int lim) {
@@ -180,16 +233,17 @@ struct FastRing {
     // round's last byte (CMAX = the most chunk boundaries RB bytes can cross), so that immediate is a sufficient
     // wait (one chunk more than necessary in the rounds that cross fewer).  Otherwise: the exact, dynamic form.
     template <int AUX, int RB, bool HINTED>
-    __device__ __forceinline__ void wait_round(int pos) {
+    __device__ __forceinline__ int32_t wait_round(int pos, int32_t K, int32_t k0, int base, int sym_bytes, bool& partial) {
         constexpr int CMAX = (RB + 1023) >> 10;
         static_assert(CMAX < kRingChunks - 1, "round too large for the ring");
+        partial = false;
         if (next == (pos >> 10) + kRingChunks) {
             wait_vmcnt<kRingChunks - 1 - CMAX>();
-        } else {
-            const int need = (pos + RB - 1) >> 10;
-            if constexpr (HINTED) fetch_through<AUX>(need);
-            wait_landed(need);
+            return K;
         }
+        if constexpr (HINTED) return holding_wait<AUX>(pos + RB - 1, K, k0, base, sym_bytes, partial);
+        wait_landed((pos + RB - 1) >> 10);
+        return K;
     }
     // refill behind a round of RBYTES bytes: every chunk wholly below the next round's first byte.  At the
     // watermark that is RBYTES >> 10 chunks or one more: straight-line requests instead of a loop.
@@ -209,18 +263,37 @@ struct FastRing {
     // once a chunk >= 16 has landed the probes have too: hold back everything behind the round group
     // whose closing probe is the first quiet one after the last loud one (amp1 = the squelch threshold
     // per sample, 0 = nothing is ever quiet; base as given to request_probes; extra = bytes a round
-    // reads past its end when re-aligning)
-    __device__ __forceinline__ void eval_probes(int need, uint32_t amp1, int base, int extra) {
+    // reads past its end when re-aligning).  REFINE: the second level (see fine_probes) -- eight probes inside that
+    // group, requested here and evaluated once a chunk requested after them has landed; `margin` bytes (one symbol)
+    // are added to the refined limit: the squelch stops at the first quiet SYMBOL, which may start behind a quiet probe.
+    template <bool REFINE = false>
+    __device__ __forceinline__ void eval_probes(int need, uint32_t amp1, int base, int extra, int margin = 0) {
         if (need < eval_need) return;
         eval_need = 0x7fffffff;
-        hint_state |= 2;
         wave_lds_sync();
-        const int step = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset));
         const u32x4 pv = *reinterpret_cast<const u32x4*>(ring + kProbeOffset + 16 * lane);
-        uint32_t a8 = 0;                                                                   // |x0| + ... + |x7|
+        uint32_t q8 = 0;                                                                   // 8 * 32768 - (|x0| + ... + |x7|)
 #pragma unroll
-        for (int j = 0; j < 4; j++) a8 = __builtin_amdgcn_sad_u16(pv[j] ^ kBias, kBias, a8);
-        const uint64_t mask = __ballot(a8 >= 8u * amp1);
+        for (int j = 0; j < 4; j++) q8 = quiet_sad(pv[j], q8);
+        const uint64_t loud = __ballot(loud_enough(q8, 8u, 8u * amp1));
+        if constexpr (REFINE) {
+            if (hint_state & 2) {                             // ---- second level: lanes 0..7 hold the sub-probes
+                if (hint_state >= 8) return;                  // a miss has moved the limit since: leave it alone
+                const int base2 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset + 4));
+                const int sub = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset + 8));
+                const uint32_t m8 = (uint32_t)loud & 0xFFu;
+                if (m8 >> 7) return;                          // loud up to the last sub-probe: the first level's limit stands
+                const int q2 = m8 ? 32 - __builtin_clz(m8) : 0;                           // first sub-probe of the quiet tail
+                const uint64_t last2 = (uint64_t)(uint32_t)base2 + (uint64_t)(uint32_t)(q2 + 1) * (uint64_t)(uint32_t)sub - 1u +
+                                       (uint32_t)(extra + margin);
+                const uint64_t lim2 = (last2 >> 10) + 1u;
+                if (lim2 < (uint64_t)(uint32_t)hint_lim) hint_lim = (int)lim2;
+                return;
+            }
+        }
+        hint_state |= 2;
+        const int step = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(ring + kHintStashOffset));
+        const uint64_t mask = loud;
         if (amp1 == 0 || (mask >> (kProbes - 1))) return;                                  // loud to the very end
         const int q = mask ? 64 - __builtin_clzll(mask) : 0;                               // first probe of the quiet tail
         // 64-bit: (q + 1) * step reaches span + 64 rounds, more than the 2^16-byte headroom of
@@ -228,6 +301,22 @@ struct FastRing {
         const uint64_t last = (uint64_t)(uint32_t)base + (uint64_t)(uint32_t)(q + 1) * (uint64_t)(uint32_t)step - 1u + (uint32_t)extra;
         const uint64_t lim = (last >> 10) + 1u;
         hint_lim = lim < 0x7fffffffull ? (int)lim : 0x7fffffff;
+        if constexpr (REFINE) {
+            // the signal ends between probe q - 1 and probe q: eight sub-probes there (one LDS-DMA instruction: lanes 0..7
+            // fetch 16 bytes each, every other lane points behind the buffer -- range-checked, no memory request)
+            const uint64_t lo64 = (uint64_t)(uint32_t)base + (uint64_t)(uint32_t)q * (uint64_t)(uint32_t)step;
+            const int sub = step >> 3;
+            if (sub >= 256 && lo64 + (uint64_t)step < 0x7fff0000ull) {
+                const int lo = (int)lo64;
+                if (lane == 0) {
+                    *reinterpret_cast<int*>(ring + kHintStashOffset + 4) = lo;
+                    *reinterpret_cast<int*>(ring + kHintStashOffset + 8) = sub;
+                }
+                const int po = lane < 8 ? lo + (lane + 1) * sub - 16 : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + kProbeOffset), 16, po, 0, 0, 0);
+                eval_need = next;                            // once a chunk requested from here on has landed, so have they
+            }
+        }
     }
 };
 
@@ -513,10 +602,10 @@ __device__ __forceinline__ uint32_t hi_sad(const uint32_t (&x)[20]) {
 }
 
 template <int D0, int D1>
-__device__ __forceinline__ uint32_t abs_sum(const uint32_t (&x)[20]) {   // ref:94-98
+__device__ __forceinline__ uint32_t quiet_sum(const uint32_t (&x)[20]) {   // 32768 n - sum|x| (ref:94-98; see quiet_sad)
     uint32_t a = 0;
 #pragma unroll
-    for (int d = D0; d < D1; d++) a = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, a);
+    for (int d = D0; d < D1; d++) a = quiet_sad(x[d], a);
     return a;
 }
 
@@ -857,9 +946,9 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         if (margins && k0 + lane < mlim) margins[k0 + lane] = (int32_t)sd - (int32_t)md;
         const int nv = (K - k0) < 64 ? (K - k0) : 64;
         rxd_pass<64>(rd, __ballot(bit), nv, k0, lane, words, out_row, out_stride, [&]() {
-            uint32_t amp = 0x7fffffffu;
-            if constexpr (!(FLAGS & 2)) amp = abs_sum<0, 20>(x);
-            return __ballot(amp >= amp_thr);
+            uint32_t q = 0u;                                    // (FLAGS & 2, a kbench ablation: always loud)
+            if constexpr (!(FLAGS & 2)) q = quiet_sum<0, 20>(x);
+            return __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
         });
     } else if constexpr (BF == 20) {          // two symbols per lane: dwords 0-9 = symbol k0 + lane,
                                               // dwords 10-19 = symbol k0 + 64 + lane (fast_rounds reads
@@ -883,8 +972,8 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         }
         const uint64_t B[2] = {__ballot(bit[0]), __ballot(bit[1])};
         rxd_round<2>(rd, B, K, k0, lane, words, out_row, out_stride, [&](int half) {
-            const uint32_t amp = half == 0 ? abs_sum<0, 10>(x) : abs_sum<10, 20>(x);
-            return __ballot(amp >= amp_thr);
+            const uint32_t q = half == 0 ? quiet_sum<0, 10>(x) : quiet_sum<10, 20>(x);
+            return __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
         });
     } else {                                  // BF = 80 / 160: two / four lanes per symbol
         static_assert(BF == 80 || BF == 160, "fast path supports bit_frames 20, 40, 80, 160");
@@ -917,8 +1006,8 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         // every LPS-th bit of the ballot, compacted on the scalar unit: bit j <- symbol j
         const uint64_t bmask = compress_bits<LPS>(__ballot(bit));
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
-            const uint32_t amp = quad_sum<LPS>(abs_sum<0, 20>(x));
-            return compress_bits<LPS>(__ballot(amp >= amp_thr));
+            const uint32_t q = quad_sum<LPS>(quiet_sum<0, 20>(x));
+            return compress_bits<LPS>(__ballot(loud_enough(q, (uint32_t)BF, amp_thr)));
         });
     }
 }
@@ -938,13 +1027,16 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
         // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
         // 10 youngest DMAs may still be in flight.
+        int32_t Kr = K;                    // symbols this round may use (fewer: a partial round, see holding_wait)
+        bool partial = false;
+        RxDeferred saved;
+        const int last = byte0 + 5120 * r + 5119 + (ALIGNED ? 0 : 16);                 // last byte read
         if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed 5-chunks-per-round schedule
-            const int need = (byte0 + 5120 * r + 5119 + (ALIGNED ? 0 : 16)) >> 10;     // chunk of the last byte read
-            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(need);
-            fr.wait_landed(need);
+            Kr = fr.template holding_wait<(FLAGS & 4) ? 0 : 2>(last, K, r * SPR, byte0, 2 * BF, partial);
+            if (partial) saved = rd;
         } else {
             fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
-            if constexpr (HINTED) fr.eval_probes(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : 16);
+            if constexpr (HINTED) fr.template eval_probes<fine_probes(5120)>(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : 16, 2 * BF);
         }
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
@@ -1016,16 +1108,23 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         // the reads above have returned (their values are in x): refill the 5 chunks this
         // round consumed right away, before the arithmetic
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (HINTED && fr.hint_takes_over(5)) {
+        if (HINTED && partial) {
+            // (no refill: the round may have to run again on the same ring contents)
+        } else if (HINTED && fr.hint_takes_over(5)) {
             fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 5120 * (r + 1)) >> 10) + kRingChunks);
         } else {
 #pragma unroll
             for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
             fr.next += 5;
         }
-        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, K, r * SPR, rd, words, out_row, out_stride,
+        fast_round_compute<BF, FLAGS>(x, lane, amp_thr, Kr, r * SPR, rd, words, out_row, out_stride,
                                       margins, mstride);
         if (rd.st.phase == 2) break;
+        if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again
+            rd = saved;
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+            r--;
+        }
     }
 }
 
@@ -1050,8 +1149,8 @@ struct MultiGeom {
 #define AFSK_R12 6
 #endif
 #ifndef AFSK_R16
-#define AFSK_R16 6
-#endif
+#define AFSK_R16 8      // r5: 8 KiB rounds of four slices, -2.2 % at 65536 streams, -2.8 % at 4096 (profiles/r5_exp10_chunks_per_round.txt;
+#endif                  // bit_frames 12: 9 against 6 neutral; 24: 9 costs 5 %; 8: 6 / 8 cost 5 % / 2 %)
 #ifndef AFSK_R24
 #define AFSK_R24 6
 #endif
@@ -1077,17 +1176,28 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
     constexpr int NR_READS = PB / RW;                          // reads per piece when aligned
     constexpr int DW = RW / 4;                                 // dwords per read
     const int lane = fr.lane;
-    const int32_t mlim = K < mstride ? K : mstride;
+    // 32-byte pieces (bit_frames 16): the sixteen lanes of a ds_read_b128 group, 32 bytes apart, pair up on eight bank
+    // quads (two-way conflict on every read).  Lanes with bit 3 set read the second 16 bytes of their piece first:
+    // the pairs then touch different quads.  Their registers hold the symbol's two halves exchanged, i.e. quarter
+    // sums (h2, h3, h0, h1): the mark correlator is symmetric under that exchange, the space correlator flips sign.
+#ifndef AFSK_SWAP16
+#define AFSK_SWAP16 0
+#endif
+    constexpr bool SWAP16 = (AFSK_SWAP16) && ALIGNED && BF == 16;
+    const bool swap16 = SWAP16 && ((lane >> 3) & 1);
     for (int r = 0; r < NR; r++) {
         // bytes [byte0 + 1024 R r, +1024 R) must have landed: at most R + 1 chunks from the oldest
         // resident one; chunks through B_r + 15 are issued, so the 15 - R youngest may be in flight
+        int32_t Kr = K;                    // symbols this round may use (fewer: a partial round, see holding_wait)
+        bool partial = false;
+        RxDeferred saved;
+        const int last = byte0 + 1024 * R * (r + 1) - 1 + (ALIGNED ? 0 : RW);            // last byte read
         if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed R-chunks-per-round schedule
-            const int need = (byte0 + 1024 * R * (r + 1) - 1 + (ALIGNED ? 0 : RW)) >> 10;   // chunk of the last byte read
-            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(need);
-            fr.wait_landed(need);
+            Kr = fr.template holding_wait<(FLAGS & 4) ? 0 : 2>(last, K, r * SPR, byte0, PB, partial);
+            if (partial) saved = rd;
         } else {
             fr.template wait_fixed<kRingChunks - 1 - R>(((byte0 + 1024 * R * r) >> 10) + R);
-            if constexpr (HINTED) fr.eval_probes(((byte0 + 1024 * R * r) >> 10) + R, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : RW);
+            if constexpr (HINTED) fr.template eval_probes<fine_probes(1024 * R)>(((byte0 + 1024 * R * r) >> 10) + R, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : RW, PB);
         }
         uint32_t x[SPL * NO];
         const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
@@ -1106,10 +1216,20 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         };
         if (nowrap) {
             const uint8_t* src = fr.ring + rb + PB * lane;
+            if constexpr (SWAP16) {
+                const uint8_t* src_a = src + (swap16 ? 16 : 0);        // read 0 takes the second half in the swapped lanes
+                const uint8_t* src_b = src + (swap16 ? 0 : 16);
+#pragma unroll
+                for (int piece = 0; piece < SPL; piece++) {
+                    read_piece(src_a + 64 * PB * piece, piece, 0);
+                    read_piece(src_b + 64 * PB * piece, piece, 1);
+                }
+            } else {
 #pragma unroll
             for (int piece = 0; piece < SPL; piece++)
 #pragma unroll
                 for (int j = 0; j < NR_READS; j++) read_piece(src + 64 * PB * piece + RW * j, piece, j);
+            }
             asm volatile("" ::: "memory");                             // (keeps the compiler from merging the two forms into selects)
         } else {
 #pragma unroll
@@ -1117,7 +1237,8 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             const int pb = rb + 64 * PB * piece + PB * lane;
             if constexpr (ALIGNED) {
 #pragma unroll
-                for (int j = 0; j < NR_READS; j++) read_piece(fr.ring + ((pb + RW * j) & (kRingBytes - 1)), piece, j);
+                for (int j = 0; j < NR_READS; j++)
+                    read_piece(fr.ring + ((pb + RW * (SWAP16 ? (j ^ (int)swap16) : j)) & (kRingBytes - 1)), piece, j);
             } else {
                 const int ab = pb & ~(RW - 1);
                 uint32_t W[NO + DW];
@@ -1154,6 +1275,7 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         }
         }
         const int k0 = r * SPR;
+        const int32_t mlim = Kr < mstride ? Kr : mstride;       // soft output rows hold symbols [0, mlim)
         uint64_t B[SPL];
         int32_t mg[SPL];                                                       // space_diff - mark_diff per slice (soft output)
         uint32_t l12[BF == 4 ? SPL : 1];                                       // bit_frames 4: the limited (sample 1, sample 2) pairs
@@ -1181,6 +1303,10 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
                     const uint32_t u = 2u * FULL * Q + hq[0] - hq[3], dd = hq[2] - hq[1];   // (modulo 2^32, like the sums)
                     mark = u + dd;
                     space = u - dd;
+                    if constexpr (SWAP16) {    // exchanged halves: hq = (h2, h3, h0, h1) -> u - 2FQ and dd trade places
+                        const uint32_t sp_swapped = 2u * FULL * Q + dd - (hq[0] - hq[3]);
+                        space = swap16 ? sp_swapped : space;
+                    }
                 } else {
 #pragma unroll
                     for (int d = 0; d < NO; d++) {
@@ -1210,7 +1336,9 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         constexpr int EARLY = (AFSK_MULTI_EARLY) < 0 ? SPL / 2 : ((AFSK_MULTI_EARLY) < SPL ? (AFSK_MULTI_EARLY) : SPL - 1);
         static_for<0, EARLY>(decide);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in x: refill
-        if (HINTED && fr.hint_takes_over(R)) {
+        if (HINTED && partial) {
+            // (no refill: the round may have to run again on the same ring contents)
+        } else if (HINTED && fr.hint_takes_over(R)) {
             fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 1024 * R * (r + 1)) >> 10) + kRingChunks);
         } else {
 #pragma unroll
@@ -1250,18 +1378,23 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             }
         }
         auto amp_word = [&](int piece) {                                       // ref:94-98, ref:375
-            uint32_t amp = 0;
+            uint32_t q = 0;
 #pragma unroll
-            for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[NO * piece + d] ^ kBias, kBias, amp);
-            return __ballot(amp >= amp_thr);
+            for (int d = 0; d < NO; d++) q = quiet_sad(x[NO * piece + d], q);
+            return __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
         };
         if constexpr (SPL == 1) {
-            const int nv = (K - k0) < 64 ? (K - k0) : 64;
+            const int nv = (Kr - k0) < 64 ? (Kr - k0) : 64;
             rxd_pass<64>(rd, B[0], nv, k0, lane, words, out_row, out_stride, [&]() { return amp_word(0); });
         } else {
-            rxd_round<SPL>(rd, B, K, k0, lane, words, out_row, out_stride, amp_word);
+            rxd_round<SPL>(rd, B, Kr, k0, lane, words, out_row, out_stride, amp_word);
         }
         if (rd.st.phase == 2) break;
+        if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again
+            rd = saved;
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+            r--;
+        }
     }
 }
 
@@ -1315,7 +1448,6 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     typedef u32x2 u32x2_a8 __attribute__((aligned(8)));
     const int lane = fr.lane;
     const int part = lane & (LPS - 1);
-    const int32_t mlim = K < mstride ? K : mstride;
     // 128-byte pieces (bit_frames 128): sixteen lanes of a ds_read_b128 group, 128 bytes apart, would meet on two
     // bank quads -- an 8-way conflict on every read (r5 PMC: 79 % of the LDS cycles of this kernel).  A lane piece
     // is two quarters of four 16-byte chunks, and inside a quarter the order of the chunks does not matter (one
@@ -1333,8 +1465,12 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
-        fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + EXTRA, HINTED>(pos);   // chunks through last >> 10 have landed
-        if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0 & ~(RW - 1), EXTRA);
+        bool partial;                                             // (a partial round: see FastRing::holding_wait)
+        RxDeferred saved;
+        const int32_t Kr = fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + EXTRA, HINTED>(pos, K, r * SPP, byte0, 2 * BF, partial);
+        if (HINTED && partial) saved = rd;
+        const int32_t mlim = Kr < mstride ? Kr : mstride;         // soft output rows hold symbols [0, mlim)
+        if constexpr (HINTED) fr.template eval_probes<fine_probes(RBYTES)>(last >> 10, amp_thr / (uint32_t)BF, byte0 & ~(RW - 1), EXTRA, 2 * BF);
         const int rb = pos & (kRingBytes - 1);                    // wave-uniform
         if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
@@ -1376,7 +1512,7 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         // every chunk wholly below the next round's first byte is free
-        fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
+        if (!(HINTED && partial)) fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
 
         const int k0 = r * SPP;
         uint32_t mark = 0, space = 0;
@@ -1434,19 +1570,24 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
         const bool bit = md < sd;                                                        // ref:348-351
         if (margins && part == 0 && k0 + lane / LPS < mlim) margins[k0 + lane / LPS] = (int32_t)sd - (int32_t)md;
-        const int nv = (K - k0) < SPP ? (K - k0) : SPP;
+        const int nv = (Kr - k0) < SPP ? (Kr - k0) : SPP;
         uint64_t bmask = __ballot(bit);
         if constexpr (LPS >= 2) bmask = compress_bits<LPS>(bmask);
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
-            uint32_t amp = 0;
+            uint32_t q = 0;
 #pragma unroll
-            for (int d = 0; d < NO; d++) amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);   // ref:94-98
-            if constexpr (LPS >= 2) amp = quad_sum<LPS>(amp);
-            uint64_t am = __ballot(amp >= amp_thr);
+            for (int d = 0; d < NO; d++) q = quiet_sad(x[d], q);                                      // ref:94-98
+            if constexpr (LPS >= 2) q = quad_sum<LPS>(q);
+            uint64_t am = __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
             if constexpr (LPS >= 2) am = compress_bits<LPS>(am);
             return am;
         });
         if (rd.st.phase == 2) break;
+        if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again
+            rd = saved;
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+            r--; pos -= RBYTES;
+        }
     }
 }
 
@@ -1541,7 +1682,6 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
     constexpr uint32_t FULL = 65535u;
     const int lane = fr.lane;
     const int part = lane & (LPS - 1), sym = lane / LPS;
-    const int32_t mlim = K < mstride ? K : mstride;
     // this lane's piece of every symbol it works on: dwords [d0, d0 + n) of quarter k
     const int k = part / LPQ, j = part % LPQ;
     const int q0 = (k * Q + 1) >> 1, q1 = ((k + 1) * Q + 1) >> 1;
@@ -1558,8 +1698,12 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
     int pos = byte0;                                              // stream byte of the round's first sample
     for (int r = 0; r < NR; r++, pos += RBYTES) {
         const int last = pos + RBYTES + 3;                        // tail slot B of the last lane reaches one dword further
-        fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + 4, HINTED>(pos);
-        if constexpr (HINTED) fr.eval_probes(last >> 10, amp_thr / (uint32_t)BF, byte0, 4);
+        bool partial;                                             // (a partial round: see FastRing::holding_wait)
+        RxDeferred saved;
+        const int32_t Kr = fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + 4, HINTED>(pos, K, r * SPP, byte0, 2 * BF, partial);
+        if (HINTED && partial) saved = rd;
+        const int32_t mlim = Kr < mstride ? Kr : mstride;         // soft output rows hold symbols [0, mlim)
+        if constexpr (HINTED) fr.template eval_probes<fine_probes(RBYTES)>(last >> 10, amp_thr / (uint32_t)BF, byte0, 4, 2 * BF);
         const int rb = pos & (kRingBytes - 1);
         if (rb + RBYTES + 4 > kRingBytes) {                       // a piece runs past the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
@@ -1604,7 +1748,7 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
             for (int d = 0; d < NB + 2; d++) x[d] = __builtin_amdgcn_alignbyte(W[d + 1], W[d], 2);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
-        fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
+        if (!(HINTED && partial)) fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);
 
         uint32_t h = 0;
 #pragma unroll
@@ -1624,21 +1768,26 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
         const uint32_t md = mark / (uint32_t)BF, sd = space / (uint32_t)BF;
         const bool bit = md < sd;                                                        // ref:348-351
         if (margins && part == LPS - 1 && k0 + sym < mlim) margins[k0 + sym] = (int32_t)sd - (int32_t)md;
-        const int nv = (K - k0) < SPP ? (K - k0) : SPP;
+        const int nv = (Kr - k0) < SPP ? (Kr - k0) : SPP;
         const uint64_t bmask = compress_bits_last<LPS>(__ballot(bit));
         // the squelch amplitude (ref:94-98, ref:375) is only formed in passes that hold data symbols -- the
         // reference does not evaluate it during training either (ref:361-366); r4: a quarter of the per-dword
         // VALU work of the training rounds
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
-            uint32_t amp = 0;
+            uint32_t q = 0;                                   // quiet sums (see quiet_sad): the lanes of a symbol add up to 32768 BF - sum|x|
 #pragma unroll
-            for (int d = 0; d <= NB; d++) amp = __builtin_amdgcn_sad_u16(x[d] ^ kBias, kBias, amp);
-            const uint32_t ab = __builtin_amdgcn_sad_u16(x[NB + 1] ^ kBias, kBias, 0u);
-            amp += two ? ab : 0u;
-            const uint32_t asum = group_sum_last<LPS>(amp);
-            return compress_bits_last<LPS>(__ballot(asum >= amp_thr));
+            for (int d = 0; d <= NB; d++) q = quiet_sad(x[d], q);
+            const uint32_t qb = quiet_sad(x[NB + 1], 0u);
+            q += two ? qb : 0u;
+            const uint32_t qsum = group_sum_last<LPS>(q);
+            return compress_bits_last<LPS>(__ballot(loud_enough(qsum, (uint32_t)BF, amp_thr)));
         });
         if (rd.st.phase == 2) break;
+        if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again
+            rd = saved;
+            fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
+            r--; pos -= RBYTES;
+        }
     }
 }
 
@@ -1850,7 +1999,7 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
             for (int u = 0; u < 4; u++) {
                 const uint32_t x = __builtin_amdgcn_alignbyte(W[u + 1], W[u], sh);
                 h = __builtin_amdgcn_sad_u16(limit_pair_biased(x), 0xFFFFFFFFu, h);         // ref:344, 346-347
-                amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);                      // ref:94-98
+                amp = quiet_sad(x, amp);                                                    // ref:94-98 (quiet sum: see quiet_sad)
             }
         }
         uint32_t prev = *reinterpret_cast<const uint32_t*>(src + 4 * d);
@@ -1859,7 +2008,7 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
             const uint32_t x = __builtin_amdgcn_alignbyte(next, prev, sh);
             prev = next;
             h = __builtin_amdgcn_sad_u16(limit_pair_biased(x), 0xFFFFFFFFu, h);
-            amp = __builtin_amdgcn_sad_u16(x ^ kBias, kBias, amp);
+            amp = quiet_sad(x, amp);
         }
         const uint32_t wa = *reinterpret_cast<const uint32_t*>(src + 4 * nb + 4);
         const uint32_t wb = *reinterpret_cast<const uint32_t*>(src + 4 * nb + 8);
@@ -1872,9 +2021,9 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
         uint32_t space = space_hi ? h : FULL * (2u * (uint32_t)nb) - h;
         mark = __builtin_amdgcn_sad_u16(la, tmA, mark);
         space = __builtin_amdgcn_sad_u16(la, tsA, space);
-        amp = __builtin_amdgcn_sad_u16(xa ^ kBias, kBias, amp);
+        amp = quiet_sad(xa, amp);
         const uint32_t mb = __builtin_amdgcn_sad_u16(lb, lm, 0u), sb = __builtin_amdgcn_sad_u16(lb, ls, 0u);
-        const uint32_t ab = __builtin_amdgcn_sad_u16(xb ^ kBias, kBias, 0u);
+        const uint32_t ab = quiet_sad(xb, 0u);
         mark += two ? mb : 0u;
         space += two ? sb : 0u;
         amp += two ? ab : 0u;
@@ -1888,7 +2037,7 @@ __device__ __forceinline__ void rt_rounds(FastRing& fr, int bf, const RtGeom& g,
         const int nv = (K - k0) < spp ? (K - k0) : spp;
         const uint64_t bmask = compress_bits_last_rt(__ballot(bit), lps);
         rxd_pass_rt(rd, bmask, nv, k0, spp, lane, words, out_row, out_stride, [&]() {
-            return compress_bits_last_rt(__ballot(amp >= amp_thr), lps);
+            return compress_bits_last_rt(__ballot(loud_enough(amp, (uint32_t)bf, amp_thr)), lps);
         });
         if (rd.st.phase == 2) break;
     }

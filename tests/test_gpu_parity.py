@@ -914,6 +914,73 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
         assert (want["nbytes"] > 0).sum() > (n // 4 if baud >= 300 else 0), baud
 
 
+def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_cuda, entry):
+    """r5: for rounds of 6 KiB and more the tail-hint probes stand closer than a round, and the round that reaches past
+    the hint is decoded from the symbols below the REQUESTED bytes first (a partial round); only if the squelch stop is
+    not among them is the rest fetched and the round run again.  6200 one-second streams per rate whose payload length
+    -- hence the position of the signal end inside its round -- sweeps from stream to stream, plus the cases that make
+    the first guess wrong: a signal that ends in the middle of a symbol, noise in the silent tail, a second burst
+    behind a gap (the hint holds back chunks that ARE needed), a level below the squelch threshold (every probe
+    quiet), a stream cut right behind the data.  Every output equals the CPU oracle's, through all three entries."""
+    import os
+    torch = torch_cuda
+    dev = "cuda:0"
+    n, total = 6200, 48000
+    threads = os.cpu_count() or 16
+    rates = (4000, 800, 375, 96, 3000, 1200) if entry == "uniform" else (4000, 800, 375, 96, 3000, 1200, 500, 6000)
+    rng = np.random.default_rng(515)
+
+    def build(bauds):
+        baud_a = np.asarray([bauds[i % len(bauds)] for i in range(n)], np.int32)
+        bf = (48000 // baud_a).astype(np.int32)
+        room = np.asarray([synth.one_second_payload(int(b)) for b in baud_a], np.int32)
+        plen = np.maximum(room - (np.arange(n) // len(bauds)) % np.maximum(room, 1), 0).astype(np.int32)   # 0 ... room bytes
+        payload = synth.payload_bytes(77, 0, n, int(room.max()))
+        ts = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_a], np.int32)
+        off = np.arange(n, dtype=np.int64) * total
+        ln = np.full(n, total, np.int32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        x = torch.zeros(n * total, dtype=torch.int16, device=dev)
+        batch.modulate_batch(t(payload), t(plen), t(bf), t(ts), t(off), t(ln), total, x, True)
+        h = x.cpu().numpy().reshape(n, total).copy()
+        for i in range(n):
+            k = i % 13
+            if k == 3:                                        # the signal ends in the middle of a symbol
+                e = int(np.flatnonzero(h[i])[-1]) if h[i].any() else 0
+                h[i, max(e - int(rng.integers(1, 2 * bf[i])), 0):] = 0
+            elif k == 5:                                      # noise in the tail, around the squelch threshold
+                e = int(np.flatnonzero(h[i])[-1]) + 1 if h[i].any() else 0
+                h[i, e:] = rng.integers(-22000, 22000, total - e)
+            elif k == 7 and plen[i] * 14 * bf[i] < 12000:     # a second burst behind a gap: held-back chunks are needed
+                e = int(np.flatnonzero(h[i])[-1]) + 1
+                gap = int(rng.integers(2000, 9000))
+                m = min(e, total - e - gap)
+                if m > 4096:
+                    h[i, e + gap: e + gap + m] = h[i, :m]
+            elif k == 9:                                      # below the squelch threshold: every probe is quiet
+                h[i] = (h[i].astype(np.int32) * 3 // 25).astype(np.int16)
+            elif k == 11:                                     # the stream ends right behind the data
+                e = int(np.flatnonzero(h[i])[-1]) + 1 if h[i].any() else total
+                ln[i] = max(min(e + int(rng.integers(0, 3 * bf[i])), total), 4096)
+        return h.reshape(-1), off, ln, bf
+
+    if entry == "uniform":
+        for baud in rates:
+            flat, off, ln, bf = build((baud,))
+            res = REAL_DEMOD_BATCH(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ln).to(dev),
+                                   48000 // baud, 14000, out_stride=64, entry="uniform")
+            torch.cuda.synchronize()
+            want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=64, n_threads=threads)
+            assert_same(res.cpu(), want, f"signal end sweep, {baud} baud")
+            assert (want["nbytes"] > 0).sum() > n // 2, baud
+    else:
+        flat, off, ln, bf = build(rates)
+        got = device_demod(torch, flat, off, ln, bf, stride=64)
+        want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=64, n_threads=threads)
+        assert_same(got, want, "signal end sweep, eight rates in one launch")
+        assert (want["nbytes"] > 0).sum() > n // 2
+
+
 @pytest.mark.parametrize("n", [6200, 8256])
 def test_uniform_runtime_geometry_large_launch(torch_cuda, entry, n):
     """The uniform kernel of the RUN-TIME geometry (bit_frames no Receiver can have -- not a divisor of

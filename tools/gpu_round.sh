@@ -11,16 +11,18 @@ T=$PROF_TAG
 if [ -z "${SKIP_TESTS:-}" ]; then
 ( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/${T}_pytest_gpu.log
 fi
+if [ -z "${PROF_ONLY:-}" ]; then
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) | tee gpurun_out/${T}_smoke.log
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/${T}_bench_main.err | grep '^{"metric"' ) > gpurun_out/${T}_bench_main.json
 cut -c1-600 gpurun_out/${T}_bench_main.json
+fi
 if [ "${1:-}" = "prof" ]; then
   R=$(pwd)
   for w in ${PROF_WL:-config5 config2 config3}; do
     steps=200; wl="--workload $w"; kern=demod
     case $w in
       config5|config3|config4) steps=20 ;;
-      custom*) wl="--workload custom --bauds ${w#custom}" ;;
+      custom*) wl="--workload custom --bauds ${w#custom} --streams ${PROF_STREAMS:-65536}"; steps=20 ;;
     esac
     rm -rf gpurun_out/prof_trace_$w gpurun_out/prof_pmc1_$w gpurun_out/prof_pmc2_$w
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace_$w -- python3 $R/bench.py $wl --sub "" --steps $steps --warmup 3 --no-cpu-baseline 2>&1 | grep '^{"metric"' | tee $R/gpurun_out/prof_bench_$w.json | cut -c1-300 )
