@@ -307,6 +307,12 @@ def read_heartbeats(hb_dir: str, world: int) -> dict:
         try:
             os.kill(int(doc["pid"]), 0)
             alive = True
+            try:                                      # an exited child its parent has not reaped yet still "exists"
+                st = open(f"/proc/{int(doc['pid'])}/stat").read()
+                if st[st.rindex(")") + 2] in "ZX":
+                    alive = False
+            except (OSError, ValueError, IndexError):
+                pass
         except ProcessLookupError:
             alive = False
         except (OSError, ValueError, KeyError):
@@ -1299,10 +1305,11 @@ def run_rank(args) -> None:
         hb.quiet = True
         hb.beat(f"failed in '{last}': {why}"[:200])
         dog.stand_down()
-        if not dog.under_launcher and rank == 0:
-            hbs = read_heartbeats(hb.dir, world)
-            print(json.dumps(failure_line(world, args.steps, args.warmup, f"rank 0: {why}", last, hbs,
-                                          read_partial(hb.dir), "rank 0")), flush=True)
+        if not dog.under_launcher:
+            # through the same claim file as the watchdog (it may be printing at this very moment: torchrun's SIGTERM
+            # and the exception the dead peer causes in a collective can arrive together): ONE line per job.  Rank 0
+            # claims at once, another rank only if nobody has after its grace period.
+            dog._maybe_print(EXIT_RANK_FAILED, why, last)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(EXIT_RANK_FAILED if not isinstance(e, SystemExit) else (e.code if isinstance(e.code, int) else 2))

@@ -228,6 +228,52 @@ def test_bench_failure_paths_end_in_one_diagnostic_line(fault, rc_name, needle):
     assert d["metric"] == bench.METRIC and d["printed_by"] == "launcher"
 
 
+def _torchrun_bench(extra_env=None, extra_args=()):
+    """bench.py launched the way the DRIVER launches it for N > 1: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` (no bench.py launcher process:
+    the ranks' own watchdogs are all there is).  Diagnostic gloo backend, both ranks on device 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+           "--share-gpu0", "--workload", "config2", "--streams", "768", "--sub", "", "--steps", "9", "--warmup", "2",
+           "--preroll-ms", "0", "--gather-every", "4", *extra_args]
+    env = dict(os.environ, **(extra_env or {}))
+    env.pop("AFSK_BENCH_LAUNCHER", None)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_bench_under_an_external_torchrun_like_the_driver():
+    """The scaling run's launch shape, rehearsed: ONE JSON line (the last thing on stdout), rc 0, both ranks seen,
+    value_no_gather next to value."""
+    import json
+    p = _torchrun_bench()
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1 and p.stdout.strip().splitlines()[-1] == lines[0], p.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["gather_check"] == [True, True]
+    assert d["value_no_gather"] > 0 and d["gather_ms"]["median"] > 0 and d["roundtrip_match_rate"] == 1.0
+    assert "incomplete" not in d and "error" not in d
+
+
+def test_bench_under_an_external_torchrun_a_dying_rank_still_yields_the_line():
+    """Rank 1 dies after building its shard (fault injection).  torchrun terminates rank 0 with SIGTERM while its main
+    thread sits in a collective that can never complete: the watchdog THREAD of rank 0 prints the diagnostic line
+    (value null, rank 1's last phase, its own Python stack) and the job exits non-zero -- no launcher of ours involved."""
+    import json
+    p = _torchrun_bench({"AFSK_BENCH_FAULT": "1:die:shard built"}, ("--deadline-s", "120"))
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["printed_by"] == "rank 0", d
+    assert "SIGTERM" in d["error"] or "rank 0" in d["error"]
+    assert d["heartbeats"]["1"]["phase"].startswith("shard built") and d["heartbeats"]["1"]["alive"] is False
+    assert len(lines[0]) < 4096
+
+
 def _ragged_rank(rank, world, port, n_total, q):
     """Two ranks on ONE device (gloo group; RCCL refuses that): unequal shards through
     dist.gather_results with the records staged through the host for the collective."""
