@@ -873,7 +873,7 @@ def large_launch_streams(n, bauds, seed):
 @pytest.mark.parametrize("n", [6200, 8256])
 def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
     """Launches of 6144+ streams run the kernels with the tail hint (kHintMinStreams), from 8192 on also
-    with the L2 warming requests behind the ring start (kWarmMinStreams, afsk_demod_fast.h); both shift
+    with the L2 warming requests behind the ring start (kWarmMinStreams, afsk_demod_ring.h); both shift
     the in-flight accounting of the rounds on every path.  6200 streams = hint only (the round loops
     switch to the dynamic wait_landed / fetch_through schedule without the warming requests in the
     count), 8256 = hint + warming.  Mixed entry: ONE launch cycling through all 16 compile-time rates

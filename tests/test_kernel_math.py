@@ -17,7 +17,7 @@ def training_cycle(bf):
 
 @pytest.mark.parametrize("bf", BFS)
 def test_sliding_correlation_identity(bf):
-    """afsk_demod_fast.h recover_clock_index_lanes: total(i) = 65535*bf + sum_j sigma_j x[i+j] and
+    """afsk_demod_sync.h recover_clock_index_lanes: total(i) = 65535*bf + sum_j sigma_j x[i+j] and
     total(i+1) - total(i) = x[i] - 2x[i+q] + 2x[i+2q] - 2x[i+3q] + 2x[i+bf] - 2x[i+bf+h] + x[i+2bf]."""
     rng = np.random.default_rng(bf)
     x = rng.integers(-32768, 32768, 4096 + 8, dtype=np.int64)
@@ -60,7 +60,7 @@ def test_first_minimum_of_truncated_mean_by_threshold(bf):
 
 @pytest.mark.parametrize("n", [40, 80, 160, 320])
 def test_mul_hi_magic_division_is_exact(n):
-    """floor(m / n) = mul_hi(m, ceil(2^36 / n)) >> 4 for every m < 2^27 (afsk_demod_fast.h)."""
+    """floor(m / n) = mul_hi(m, ceil(2^36 / n)) >> 4 for every m < 2^27 (afsk_demod_sync.h)."""
     M = ((1 << 36) + n - 1) // n
     assert M < (1 << 32)
     for lo in range(0, 1 << 27, 1 << 22):                                      # exhaustive, in 32 MB slabs
@@ -89,7 +89,7 @@ def test_small_quarter_reciprocal_multiply_is_exact():
 
 def test_limiter_sad_identity():
     """Phase B: SAD of the limited samples against a lo template = 65535*n - SAD against the hi
-    template, so quarter sums h0..h3 against 'hi' give both correlators (afsk_demod_fast.h)."""
+    template, so quarter sums h0..h3 against 'hi' give both correlators (afsk_demod_phasec.h / afsk_demod_rounds_*.h)."""
     rng = np.random.default_rng(7)
     for bf in BFS:
         q = bf // 4
@@ -124,7 +124,7 @@ def _compress(x, lps):
 
 
 def test_scalar_bit_compaction():
-    """compress_bits<LPS> (afsk_demod_fast.h): bit j of the result = bit j*LPS of the ballot."""
+    """compress_bits<LPS> (afsk_demod_phasec.h): bit j of the result = bit j*LPS of the ballot."""
     rng = np.random.default_rng(3)
     for lps in (2, 4):
         for _ in range(500):
@@ -160,7 +160,7 @@ def test_hamming_popcount_syndrome():
         assert pos == s2 * 4 + s1 * 2 + s0
 
 
-# ---- general-piece geometry (afsk_demod_fast.h GpGeom / gp_rounds) -----------------------------------
+# ---- general-piece geometry (afsk_demod_rounds_gp.h GpGeom / gp_rounds) -----------------------------------
 GP_BFS = (128, 192, 200, 300, 384, 400, 500, 600, 640, 800, 960, 1000, 1200, 1500, 1600, 1920, 2000)
 
 
@@ -265,3 +265,45 @@ def test_bit_frames_4_decision_is_a_level_comparison():
         md = int(sum(abs(t - v) for t, v in zip(mark_t, s)) / 4)
         sd = int(sum(abs(t - v) for t, v in zip(space_t, s)) / 4)
         assert (md < sd) == (s[1] < s[2]), s
+
+
+def test_two_codeword_bit_sliced_hamming_decode():
+    """afsk_demod_phasec.h hamming_byte (r5): both Hamming(7,4) codewords of an output byte decoded in the same registers --
+    parity checks bit-sliced through c ^ (c >> 4) and c ^ (c >> 1), error positions at bits 0-2 / 7-9, v_bfrev to line
+    the data bits up.  All 2^14 received words against the per-codeword syndrome decode of ref:145-151, plus the funnel
+    shift that takes the 14 bits out of two neighbouring dwords of the bit buffer."""
+    def ref_nibble(cw):                      # bit t of cw = received bit t (ref:146-151)
+        s0 = bin(cw & 0x55).count("1") & 1
+        s1 = bin(cw & 0x66).count("1") & 1
+        s2 = bin(cw & 0x78).count("1") & 1
+        pos = s2 * 4 + s1 * 2 + s0
+        if pos:
+            cw ^= 1 << (pos - 1)
+        return ((cw >> 2) & 1) << 3 | ((cw >> 4) & 1) << 2 | ((cw >> 5) & 1) << 1 | ((cw >> 6) & 1), pos
+
+    def bitrev32(x):
+        return int(format(x & 0xFFFFFFFF, "032b")[::-1], 2)
+
+    for c in range(1 << 14):
+        t1, t2 = c ^ (c >> 4), c ^ (c >> 1)
+        a = t1 >> 2
+        s0, s1, s2 = t1 ^ a, (t1 >> 1) ^ a, (t2 >> 3) ^ (t2 >> 5)
+        pos2 = (s0 & 0x81) | ((s1 & 0x81) << 1) | ((s2 & 0x81) << 2)
+        p0, p1 = pos2 & 7, (pos2 >> 7) & 7
+        fixed = c ^ ((1 << p0) >> 1) ^ (((1 << p1) >> 1) << 7)
+        rev = bitrev32(fixed)
+        hi = ((rev >> 25) & 7) | ((rev >> 26) & 8)
+        lo = ((rev >> 18) & 7) | ((rev >> 19) & 8)
+        n0, q0 = ref_nibble(c & 127)
+        n1, q1 = ref_nibble(c >> 7)
+        assert (hi, lo, p0, p1) == (n0, n1, q0, q1), c
+        assert (pos2 >> 7) == p1                                      # what the kernel tests for "second codeword corrected"
+    # the funnel shift: 14 bits from bit g of a 4096-bit circular buffer of dwords
+    rng = np.random.default_rng(14)
+    bits = rng.integers(0, 2, 4096)
+    dw = [int(sum(int(bits[32 * i + k]) << k for k in range(32))) for i in range(128)]
+    for g in list(range(0, 4096, 7)) + [4095, 4090, 4083]:
+        w0, w1 = dw[(g >> 5) & 127], dw[((g >> 5) + 1) & 127]
+        c = (((w1 << 32) | w0) >> (g & 31)) & 0x3FFF                 # v_alignbit_b32(w1, w0, g & 31) & 0x3FFF
+        want = sum(int(bits[(g + k) % 4096]) << k for k in range(14))
+        assert c == want, g
