@@ -18,7 +18,12 @@
  *    data pointers are DEVICE pointers of the current HIP device and the call
  *    is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream);
  *  - there is no CPU fallback: without a HIP device every compute entry fails
- *    with AFSK_E_NO_DEVICE.
+ *    with AFSK_E_NO_DEVICE;
+ *  - host threads (the I/O pool of the file entries, the staging copies of the
+ *    _host entries) are sized by the CPUs the process may really use: the
+ *    cgroup CPU quota / affinity mask, divided by LOCAL_WORLD_SIZE when that is
+ *    set (one process per GPU: the ranks of a node share the node's CPUs);
+ *    AFSK_IO_THREADS / AFSK_COPY_THREADS override.
  */
 #ifndef AFSK_AMD_H
 #define AFSK_AMD_H
