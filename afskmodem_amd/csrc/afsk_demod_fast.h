@@ -89,6 +89,11 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
         // contiguous lane windows wherever the register file takes them (a 300-baud lane window does
         // not: 72 + 320 samples), sub-windows in steps otherwise
         constexpr bool LANES_FORM = BF <= 120;         // 160 / 240 / 320 / 480: sub-windows in steps
+#ifndef AFSK_NO_ZERO_SHORTCUT
+        if (clock_index_is_zero<BF, PRE>(fr))          // the training sequence starts at sample 0: no search (ref:332-337)
+            ci = 0;
+        else
+#endif
         if constexpr (LANES_FORM)
             ci = recover_clock_index_lanes<BF, false, PRE>(fr, nullptr, (FLAGS & 64) ? stamps : nullptr);
         else

@@ -116,6 +116,42 @@ __device__ __forceinline__ int recover_clock_index_lanes(FastRing& fr, uint32_t*
     return (int)__builtin_amdgcn_readfirstlane(cand);
 }
 
+// ---- phase A, the answer that needs no search (r5) -----------------------------------------------
+// int(total(0) / N) == 0 -- the stream starts with the training sequence, sample for sample within a total of N -- is a
+// mean no other offset can undercut (the means are sums of absolute values) at the first index there is: the
+// reference's loop (ref:328-337: first index of the minimum, strict <) returns 0 whatever the other 4000 offsets
+// hold.  That is every file Transmitter.save writes at 300 / 600 / 1200 baud ... (the training sequence starts at
+// frame 0, ref:457; at 2400 baud the .wav writer's quirk leaves total(0) = 3276 * N and the search runs), and it is
+// known as soon as the FIRST chunk(s) of the ring have landed: 64 lanes take one dword of the template span each,
+// one wave reduction -- ~25 instructions instead of ~900, and the seven other chunks are not waited for.
+template <int BF, int PRE = kRingChunks>
+__device__ __forceinline__ bool clock_index_is_zero(FastRing& fr) {
+    constexpr int N = 2 * BF, Q = BF / 4, H = BF / 2;
+    constexpr uint32_t C = 65535u * (uint32_t)BF;
+    constexpr int need = (2 * N - 1) >> 10;                   // chunk holding the last byte of the template span
+    static_assert(need < 8, "the template span lies inside the sync window");
+    fr.template wait_exact<PRE - 1 - need>(need);
+    const int lane = fr.lane;
+    int32_t a = 0;
+#pragma unroll
+    for (int it = 0; it < (BF + 63) / 64; it++) {
+        const int m = lane + 64 * it;                         // dword m = samples 2m, 2m + 1
+        const int mc = m < BF ? m : 0;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(fr.ring + 4 * mc);
+        uint32_t cf = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int j = 2 * mc + half;
+            const bool hi = j < BF ? (((j / Q) & 1) == 0) : ((j - BF) < H);    // template 32767 here (ref:80-91)
+            cf |= (hi ? 0xFFFFu : 0x0001u) << (16 * half);                     // sigma = -1 where it is
+        }
+        const int32_t v = dot2_i16(w, cf, 0);
+        a += m < BF ? v : 0;
+    }
+    const int32_t sum = __builtin_amdgcn_readlane(wave_incl_scan_dpp(a), 63);
+    return C + (uint32_t)sum < (uint32_t)N;                   // total(0) < N  <=>  int(total(0) / N) == 0
+}
+
 // ---- phase A, lane-wise form in steps (bit_frames 160) -----------------------------------
 // A 300-baud lane window (72 + 320 samples) does not fit the register file, so the search runs
 // in steps of 64 * GC offsets with GC = 24 per lane: a lane loads only the seven GC-sample

@@ -914,6 +914,38 @@ def test_large_launch_arms_l2_warming_on_every_path(torch_cuda, entry, n):
         assert (want["nbytes"] > 0).sum() > (n // 4 if baud >= 300 else 0), baud
 
 
+def test_clock_index_zero_without_a_search_boundaries(torch_cuda, entry):
+    """r5: int(total(0) / N) == 0 is a mean no offset can undercut at the first index there is, so the kernels return
+    clock index 0 without running the search (clock_index_is_zero).  The boundary: the first sample of a clean stream
+    lowered by d gives total(0) = d exactly -- d = N - 1 still takes the shortcut, d = N does not (mean 1: the search must
+    find whatever the reference finds, here an equal mean further on or offset 0 again); plus a stream whose copy of the
+    training sequence starts one training period late (offset 0 is then NOT the minimum).  Every output equals the oracle's."""
+    torch = torch_cuda
+    streams, bfs = [], []
+    for baud in (1200, 300, 600, 160, 800, 6000, 375):
+        bf = 48000 // baud
+        n2 = 2 * bf
+        t = afskmodem.Transmitter(baud, 0.2)
+        base = t.frames(b"ok!")                                   # ideal frames: total(0) == 0
+        for d in (0, 1, n2 - 1, n2, n2 + 1, 2 * n2 - 1, 2 * n2, 3 * n2 + 5):
+            x = base.copy()
+            x[0] = np.int16(32767 - min(d, 65535))                # template is +32767 at sample 0: |32767 - x0| = d
+            streams.append(x); bfs.append(bf)
+        late = np.concatenate([np.zeros(n2, np.int16), base])     # the sequence starts one training period late
+        streams.append(late); bfs.append(bf)
+        noisy0 = base.copy()
+        noisy0[: n2] = (noisy0[: n2].astype(np.int32) * 9 // 10).astype(np.int16)   # total(0) far above N, still the minimum region
+        streams.append(noisy0); bfs.append(bf)
+    ln = np.array([len(x) for x in streams], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    flat = np.concatenate(streams)
+    bf = np.array(bfs, np.int32)
+    got = device_demod(torch, flat, off, ln, bf, stride=16)
+    want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=16)
+    assert_same(got, want, "clock index 0 shortcut boundaries")
+    assert (want["clock_idx"] == 0).sum() >= 7 * 3 and (want["clock_idx"] > 0).sum() >= 7
+
+
 def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_cuda, entry):
     """r5: for rounds of 6 KiB and more the tail-hint probes stand closer than a round, and the round that reaches past
     the hint is decoded from the symbols below the REQUESTED bytes first (a partial round); only if the squelch stop is
