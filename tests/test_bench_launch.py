@@ -187,9 +187,8 @@ def test_launcher_counts_gpus_without_torch():
     import bench
     n = bench.visible_gpus()
     assert n is None or n >= 0
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    launcher = src[src.index("def self_launch"):src.index("class Watchdog")]
-    assert "import torch" not in launcher and "torch.cuda" not in launcher
+    src = open(os.path.join(ROOT, "tools", "bench_launch.py")).read()     # launcher, heartbeats, watchdog: no torch at all
+    assert "def self_launch" in src and "import torch" not in src and "torch.cuda" not in src
 
 
 def test_rank_side_without_a_gpu_prints_one_diagnostic_line():
@@ -338,3 +337,24 @@ def test_cpu_baseline_calibration_is_a_tracked_artefact():
     full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
     full["cpu_baseline"]["calibration"] = cal
     assert bench.compact_line(full, None)["cpu_baseline"]["calibration"] == cal
+
+
+def test_rider_rows_live_outside_bench_py_and_import_on_cpu():
+    """bench.py (launcher, headline, configs 2-4, cpu_baseline) stays small; the f1 / f2 / f3 / f5 rows and the per-rate
+    tables live in tools/bench_rows.py, are imported lazily and run inside try / except (a failing rider becomes
+    {"error": ...}: tests/test_gpu_multi.py checks that on the GPU)."""
+    import importlib
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    rows = importlib.import_module("bench_rows")
+    for fn in ("measure_modulate", "measure_gate", "measure_wav_ingest", "measure_wav_egress", "measure_rates"):
+        assert callable(getattr(rows, fn)) and not hasattr(bench, fn), fn
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import bench_rows" in src and src.count("def rider(") == 1
+    assert len(src.splitlines()) < 1400
+    # a failed rider's summary is its error, nothing else -- and the line stays parseable
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_n1.json")))
+    full["sub_records"]["f3_wav_ingest"] = {"error": "OSError: [Errno 2] No such file or directory: '/proc/afsk_no_such_dir'"}
+    line = bench.compact_line(full, None)
+    assert line["sub_records"]["f3_wav_ingest"] == {"error": full["sub_records"]["f3_wav_ingest"]["error"][:120]}
+    assert line["value"] == full["value"] and len(json.dumps(line)) < bench.LINE_CAP

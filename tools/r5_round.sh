@@ -3,6 +3,7 @@
 # FETCH_SIZE + WRITE_SIZE, one run each) for the headline, configs 2 / 3, the slowest rates and the mixed-rate cases
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp PROF_TAG=r5
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) | tee gpurun_out/r5_smoke.log
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/r5_bench_main.err | grep '^{"metric"' ) > gpurun_out/r5_bench_main.json
 cut -c1-400 gpurun_out/r5_bench_main.json; cp gpurun_out/bench_full_n1.json gpurun_out/r5_bench_full_n1.json
 SKIP_TESTS=1 PROF_ONLY=1 PROF_WL="config5 config2 config3 custom4000 custom3000 custom12000 custom375,160,96,1200" bash tools/gpu_round.sh prof r5 2>&1 | tail -60
