@@ -50,8 +50,10 @@ __device__ __forceinline__ void rxd_init(RxDeferred& d) {
 
 // squelch stop inside a pass whose data symbols start at `start` (ref:372-376)
 __device__ __forceinline__ void rxd_stop(RxDeferred& d, uint64_t amp_ok, int start, int nv, int k0) {
+    const uint64_t quiet = ~amp_ok;
+    if (quiet == 0) return;           // every symbol loud: all data passes of a stream but its last (r5: two scalar instructions instead of ten)
     const uint64_t valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-    const uint64_t stop = valid & ~((1ull << start) - 1ull) & ~amp_ok;     // start < 64
+    const uint64_t stop = valid & ~((1ull << start) - 1ull) & quiet;       // start < 64
     if (stop) {
         d.end_sym = k0 + __builtin_ctzll(stop);
         d.st.phase = 2;
@@ -221,10 +223,14 @@ __device__ __forceinline__ void spread_words(const uint64_t (&B)[SPL], uint32_t&
 // left on the scalar unit is "any hit?" (one ballot) and, once per stream each, locating the first
 // terminator / first quiet symbol.  amp_word(p) returns the "loud enough" ballot of slice p and is
 // only evaluated from the round with the terminator on, like the reference (ref:361-366).
-template <int SPL, class AmpFn>
+// all_loud() is this lane's "every one of my SPL symbols is loud enough" (the largest of their quiet sums against the
+// threshold): only a round in which some lane says no -- the stream's last, normally -- forms the SPL amplitude words,
+// spreads them over the lanes and locates the first quiet symbol (r5: 27 instead of 70 instructions per data round at
+// 12000 baud; symbols before the data or past the end can only send a round down the exact path, never past it).
+template <int SPL, class AmpFn, class AllLoudFn>
 __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL], int32_t K, int k0,
                                           int lane, unsigned long long* words, uint8_t* out_row,
-                                          int out_stride, AmpFn&& amp_word) {
+                                          int out_stride, AmpFn&& amp_word, AllLoudFn&& all_loud) {
     static_assert(SPL >= 2 && SPL <= 16, "one DPP row");
     // word p of the round goes to lane p: one v_writelane_b32 per half (r5; r4 moved every half through a
     // v_mov + v_cndmask pair -- 4 * SPL instructions per round, as many as the decisions themselves at 12000 baud)
@@ -270,7 +276,7 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
     } else if (d.st.phase == 1) {
         start = 0;
     }
-    if (start >= 0 && start < nv) {                            // squelch stop (ref:372-376)
+    if (start >= 0 && start < nv && __ballot(!all_loud()) != 0) {          // squelch stop (ref:372-376)
         uint64_t A[SPL];
 #pragma unroll
         for (int p = 0; p < SPL; p++) A[p] = amp_word(p);
@@ -357,6 +363,23 @@ __device__ __forceinline__ uint64_t compress_bits(uint64_t x) {
         x = (x | (x >> 30)) & 0x000000000000000Full;
     }
     return x;
+}
+
+// The "loud enough" ballot of a pass with LPS lanes per symbol -> one bit per symbol (bit 0 / the LAST lane of each
+// group carries the symbol's sum).  All data passes of a stream but its last have no quiet symbol: the 10 - 18 scalar
+// instructions of the compaction are only spent when one of the deciding lanes is quiet (r5; all ones = nothing to
+// stop, see rxd_stop).
+template <int LPS, bool LAST, class CompressFn>
+__device__ __forceinline__ uint64_t amp_ok_word(uint64_t loud, CompressFn&& compress) {
+    if constexpr (LPS == 1) {
+        return loud;
+    } else {
+        uint64_t sel = 0;
+#pragma unroll
+        for (int g = 0; g < 64; g += LPS) sel |= 1ull << (g + (LAST ? LPS - 1 : 0));
+        if ((~loud & sel) == 0) return ~0ull;
+        return compress(loud);
+    }
 }
 
 }  // namespace afsk

@@ -61,6 +61,9 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         rxd_round<2>(rd, B, K, k0, lane, words, out_row, out_stride, [&](int half) {
             const uint32_t q = half == 0 ? quiet_sum<0, 10>(x) : quiet_sum<10, 20>(x);
             return __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
+        }, [&]() {
+            const uint32_t q0 = quiet_sum<0, 10>(x), q1 = quiet_sum<10, 20>(x);
+            return loud_enough(q0 > q1 ? q0 : q1, (uint32_t)BF, amp_thr);
         });
     } else {                                  // BF = 80 / 160: two / four lanes per symbol
         static_assert(BF == 80 || BF == 160, "fast path supports bit_frames 20, 40, 80, 160");
@@ -94,7 +97,7 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
         const uint64_t bmask = compress_bits<LPS>(__ballot(bit));
         rxd_pass<SPP>(rd, bmask, nv, k0, lane, words, out_row, out_stride, [&]() {
             const uint32_t q = quad_sum<LPS>(quiet_sum<0, 20>(x));
-            return compress_bits<LPS>(__ballot(loud_enough(q, (uint32_t)BF, amp_thr)));
+            return amp_ok_word<LPS, false>(__ballot(loud_enough(q, (uint32_t)BF, amp_thr)), [](uint64_t b) { return compress_bits<LPS>(b); });
         });
     }
 }

@@ -193,7 +193,7 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
             const uint32_t qb = quiet_sad(x[NB + 1], 0u);
             q += two ? qb : 0u;
             const uint32_t qsum = group_sum_last<LPS>(q);
-            return compress_bits_last<LPS>(__ballot(loud_enough(qsum, (uint32_t)BF, amp_thr)));
+            return amp_ok_word<LPS, true>(__ballot(loud_enough(qsum, (uint32_t)BF, amp_thr)), [](uint64_t b) { return compress_bits_last<LPS>(b); });
         });
         if (rd.st.phase == 2) break;
         if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again

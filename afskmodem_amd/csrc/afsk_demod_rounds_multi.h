@@ -233,11 +233,22 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
             for (int d = 0; d < NO; d++) q = quiet_sad(x[NO * piece + d], q);
             return __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
         };
+        auto all_loud = [&]() {                                                // the largest quiet sum of this lane's SPL symbols
+            uint32_t qm = 0;
+#pragma unroll
+            for (int piece = 0; piece < SPL; piece++) {
+                uint32_t q = 0;
+#pragma unroll
+                for (int d = 0; d < NO; d++) q = quiet_sad(x[NO * piece + d], q);
+                qm = q > qm ? q : qm;
+            }
+            return loud_enough(qm, (uint32_t)BF, amp_thr);
+        };
         if constexpr (SPL == 1) {
             const int nv = (Kr - k0) < 64 ? (Kr - k0) : 64;
             rxd_pass<64>(rd, B[0], nv, k0, lane, words, out_row, out_stride, [&]() { return amp_word(0); });
         } else {
-            rxd_round<SPL>(rd, B, Kr, k0, lane, words, out_row, out_stride, amp_word);
+            rxd_round<SPL>(rd, B, Kr, k0, lane, words, out_row, out_stride, amp_word, all_loud);
         }
         if (rd.st.phase == 2) break;
         if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again

@@ -184,9 +184,7 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
 #pragma unroll
             for (int d = 0; d < NO; d++) q = quiet_sad(x[d], q);                                      // ref:94-98
             if constexpr (LPS >= 2) q = quad_sum<LPS>(q);
-            uint64_t am = __ballot(loud_enough(q, (uint32_t)BF, amp_thr));
-            if constexpr (LPS >= 2) am = compress_bits<LPS>(am);
-            return am;
+            return amp_ok_word<LPS, false>(__ballot(loud_enough(q, (uint32_t)BF, amp_thr)), [](uint64_t b) { if constexpr (LPS >= 2) return compress_bits<LPS>(b); else return b; });
         });
         if (rd.st.phase == 2) break;
         if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again

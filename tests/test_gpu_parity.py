@@ -1013,6 +1013,73 @@ def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_
         assert (want["nbytes"] > 0).sum() > n // 2
 
 
+def test_squelch_stop_at_every_symbol_position_of_a_round(torch_cuda, entry):
+    """r5: the squelch test of a data round / pass first asks one question per lane -- is the LARGEST quiet sum of my
+    symbols still loud enough? (one zero test on the raw ballot where several lanes share a symbol) -- and only a round
+    in which some lane says no forms the per-symbol amplitude words and locates the first quiet symbol.  Stream i of
+    every rate has ONE symbol dimmed: symbol i - 8 counted from the first data symbol (the first eight lie in the
+    training sequence and the terminator, where the reference does not look at the amplitude: ref:361-366), so the
+    quiet symbol visits every lane and every piece of two 12000-baud rounds; a third of them are zeroed, a third
+    scaled to just below the threshold, a third to just above it (no stop).  Rates: every phase-C family (ten / five /
+    eight / four / two symbols per lane, one symbol per lane, two / four lanes per symbol, word-multiple and general
+    pieces).  Every output equals the CPU oracle's."""
+    import os
+    torch = torch_cuda
+    dev = "cuda:0"
+    total = 48000
+    threads = os.cpu_count() or 16
+    rates = (12000, 6000, 4000, 3000, 1500, 2400, 1200, 600, 300, 500, 160, 96)
+
+    def build(baud):
+        bf = 48000 // baud
+        room = synth.one_second_payload(baud)
+        n = min(1400, 14 * room + 40)
+        payload = synth.payload_bytes(91, 0, n, room)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        off = np.arange(n, dtype=np.int64) * total
+        ln = np.full(n, total, np.int32)
+        x = torch.zeros(n * total, dtype=torch.int16, device=dev)
+        batch.modulate_batch(t(payload), t(np.full(n, room, np.int32)), t(np.full(n, bf, np.int32)),
+                             t(np.full(n, synth.ts_cycles_for(baud), np.int32)), t(off), t(ln), total, x, True)
+        h = x.cpu().numpy().reshape(n, total).copy()
+        clean = O.demod_batch(h[0], np.zeros(1, np.int64), ln[:1], np.full(1, bf, np.int32), 14000, out_stride=8)
+        term = int(clean["term_frame"][0])
+        assert term > 0 and clean["nbytes"][0] == room, (baud, term)
+        for i in range(n):
+            s0 = term + (i - 8) * bf
+            if s0 < 0 or s0 + bf > total:
+                continue
+            sym = h[i, s0:s0 + bf].astype(np.float64)
+            if i % 3 == 0:
+                sym[:] = 0
+            else:
+                mean = np.abs(sym).mean()
+                sym *= (14000.0 + (-0.6 if i % 3 == 1 else 0.6)) / max(mean, 1.0)
+            h[i, s0:s0 + bf] = np.clip(np.rint(sym), -32768, 32767).astype(np.int16)
+        return h.reshape(-1), off, ln, np.full(n, bf, np.int32)
+
+    if entry == "uniform":
+        for baud in rates:
+            flat, off, ln, bf = build(baud)
+            res = REAL_DEMOD_BATCH(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ln).to(dev),
+                                   48000 // baud, 14000, out_stride=64, entry="uniform")
+            torch.cuda.synchronize()
+            want = O.demod_batch(flat, off, ln, bf, 14000, out_stride=64, n_threads=threads)
+            assert_same(res.cpu(), want, f"dimmed symbol sweep, {baud} baud")
+            stopped = (want["nbits"] < 14 * synth.one_second_payload(baud)).sum()
+            assert stopped >= min(len(ln) // 4, 8), (baud, stopped)     # the zeroed and the just-below symbols do stop the decode
+    else:
+        parts = [build(b) for b in rates]
+        flat = np.concatenate([p[0] for p in parts])
+        ln = np.concatenate([p[2] for p in parts])
+        bf = np.concatenate([p[3] for p in parts])
+        off = np.arange(len(ln), dtype=np.int64) * total
+        perm = np.random.default_rng(4).permutation(len(ln))    # rates interleaved: the grouped entry sorts them back
+        got = device_demod(torch, flat, off[perm], ln[perm], bf[perm], stride=64)
+        want = O.demod_batch(flat, off[perm], ln[perm], bf[perm], 14000, out_stride=64, n_threads=threads)
+        assert_same(got, want, "dimmed symbol sweep, twelve rates in one launch")
+
+
 @pytest.mark.parametrize("n", [6200, 8256])
 def test_uniform_runtime_geometry_large_launch(torch_cuda, entry, n):
     """The uniform kernel of the RUN-TIME geometry (bit_frames no Receiver can have -- not a divisor of
