@@ -71,8 +71,7 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     fr.lane = lane;
     // the lane-wise clock recovery needs no LDS of its own: the whole ring is requested at once
     constexpr int PRE = kRingChunks;
-#pragma unroll
-    for (int c = 0; c < PRE; c++) fr.template issue<(FLAGS & 4) ? 0 : 2>(c);
+    fr.template issue_run<(FLAGS & 4) ? 0 : 2, PRE>(0);
     fr.next = PRE;
     if (warm) {
 #pragma unroll

@@ -76,6 +76,15 @@ __device__ __forceinline__ bool loud_enough(uint32_t quiet, uint32_t n_samples, 
 #endif
 __host__ __device__ constexpr bool fine_probes(int round_bytes) { return round_bytes >= (AFSK_REFINE_FROM); }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct FastRing {
     __amdgpu_buffer_rsrc_t rsrc;   // whole stream: base = sample 0, num_records = 2*len
     uint8_t* ring;                 // wave-uniform LDS base of the 16 KiB ring
@@ -104,6 +113,26 @@ struct FastRing {
     __device__ __forceinline__ void issue(int c) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + (c & (kRingChunks - 1)) * 1024),
                                                  16, lane * 16, c * 1024, 0, AUX);
+    }
+
+    // N consecutive chunks from chunk c on (r5).  The instruction's 12-bit immediate offset moves BOTH ends of an
+    // LDS-DMA transfer (global address and LDS address = M0 + offset + 16 * lane), so while the N ring slots do not
+    // wrap -- three rounds of four with five chunks per round -- ONE M0 and ONE scalar offset serve four requests
+    // (offset:0 / 1024 / 2048 / 3072): 1 + 1 scalar instructions per four chunks instead of three or four per
+    // chunk (slot mask, M0, the hazard nop, the next offset).
+    template <int AUX, int N>
+    __device__ __forceinline__ void issue_run(int c) {
+        const int slot = c & (kRingChunks - 1);
+        if (slot + N <= kRingChunks) {
+            static_for<0, N>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AFSK_LDS(ring + slot * 1024 + (j / 4) * 4096), 16, lane * 16,
+                                                         c * 1024 + (j / 4) * 4096, (j % 4) * 1024, AUX);
+            });
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; j++) issue<AUX>(c + j);
+        }
     }
 
     // ---- tail hint (see kProbes) ----  (state kept small: the round loops are short of scalar registers)
@@ -220,8 +249,7 @@ struct FastRing {
         constexpr int CMIN = RBYTES >> 10;
         const int lim = ((pos + RBYTES) >> 10) + kRingChunks;
         if (next == (pos >> 10) + kRingChunks && (!HINTED || lim <= hint_lim)) {
-#pragma unroll
-            for (int j = 0; j < CMIN; j++) issue<AUX>(next + j);
+            issue_run<AUX, CMIN>(next);
             next += CMIN;
             if (next < lim) { issue<AUX>(next); next++; }
         } else {
@@ -289,14 +317,6 @@ struct FastRing {
 };
 
 // ------------------------------------------------------------------ phase A (fast)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18,448 B of LDS per wave
 
 // ---- register re-alignment helpers (phase A sub-windows, phase B pieces) ----

@@ -203,8 +203,7 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         } else if (HINTED && fr.hint_takes_over(5)) {
             fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 5120 * (r + 1)) >> 10) + kRingChunks);
         } else {
-#pragma unroll
-            for (int j = 0; j < 5; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+            fr.template issue_run<(FLAGS & 4) ? 0 : 2, 5>(fr.next);
             fr.next += 5;
         }
         fast_round_compute<BF, FLAGS>(x, lane, amp_thr, Kr, r * SPR, rd, words, out_row, out_stride,

@@ -191,8 +191,7 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         } else if (HINTED && fr.hint_takes_over(R)) {
             fr.template top_up<(FLAGS & 4) ? 0 : 2>(((byte0 + 1024 * R * (r + 1)) >> 10) + kRingChunks);
         } else {
-#pragma unroll
-            for (int j = 0; j < R; j++) fr.template issue<(FLAGS & 4) ? 0 : 2>(fr.next + j);
+            fr.template issue_run<(FLAGS & 4) ? 0 : 2, R>(fr.next);
             fr.next += R;
         }
         static_for<0, SPL>(decide);

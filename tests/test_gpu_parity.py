@@ -1040,7 +1040,7 @@ def test_squelch_stop_at_every_symbol_position_of_a_round(torch_cuda, entry):
         ln = np.full(n, total, np.int32)
         x = torch.zeros(n * total, dtype=torch.int16, device=dev)
         batch.modulate_batch(t(payload), t(np.full(n, room, np.int32)), t(np.full(n, bf, np.int32)),
-                             t(np.full(n, synth.ts_cycles_for(baud), np.int32)), t(off), t(ln), total, x, True)
+                             t(np.full(n, synth.ts_cycles_for(baud), np.int32)), t(off), t(ln), total, x, False)   # (no .wav quirk: it wipes out the 12000-baud mark tone)
         h = x.cpu().numpy().reshape(n, total).copy()
         clean = O.demod_batch(h[0], np.zeros(1, np.int64), ln[:1], np.full(1, bf, np.int32), 14000, out_stride=8)
         term = int(clean["term_frame"][0])
