@@ -126,6 +126,12 @@ def main() -> None:
         us = e0.elapsed_time(e1) / k * 1e3
         med = {kk: sorted(v)[len(v) // 2] for kk, v in samples.items() if v}
         rng = {kk: (min(v), max(v)) for kk, v in samples.items() if v}
+        # sysfs shows every card of the host: this job's is the one whose memory is busy
+        cards = sorted({kk.split(".")[0] for kk in med})
+        if cards:
+            mine = max(cards, key=lambda c: med.get(c + ".mem_busy_percent", 0.0))
+            med = {kk: v for kk, v in med.items() if kk.startswith(mine + ".")}
+            rng = {kk: v for kk, v in rng.items() if kk.startswith(mine + ".")}
         row = {"baud": baud, "launches": k, "us_per_launch": round(us, 2), "median": med, "range": rng, "rocm_smi": smi}
         rows.append(row)
         print(json.dumps(row))
