@@ -1013,6 +1013,40 @@ def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_
         assert (want["nbytes"] > 0).sum() > n // 2
 
 
+def test_output_buffer_spills_with_the_tail_hint_armed(torch_cuda, entry):
+    """r5: decoded bytes wait in a 1 KiB LDS buffer for the end of the stream and are spilled whenever it is full.
+    Launches large enough to arm the tail hint (partial rounds that run twice: the receiver state goes back, the
+    spilled prefix does not) of streams whose output is longer than the buffer -- 1.1 to 3.3 KiB -- with payload
+    lengths that move the signal end through the rounds and the buffer boundary through the flush batches."""
+    import os
+    torch = torch_cuda
+    dev = "cuda:0"
+    threads = os.cpu_count() or 16
+    n = 8256
+    for baud, total in ((12000, 110000), (6000, 200000), (3000, 336000)):
+        if entry == "uniform" and baud != 12000:
+            continue                                  # (the uniform kernels of 6000 baud arm the hint from 16384 streams on)
+        bf = 48000 // baud
+        room = synth.one_second_payload(baud, stream_len=total)
+        assert room > 1100, (baud, room)
+        plen = (room - (np.arange(n) * 7) % 400).astype(np.int32)
+        payload = synth.payload_bytes(123, 0, n, room)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        off = np.arange(n, dtype=np.int64) * total
+        ln = np.full(n, total, np.int32)
+        x = torch.zeros(n * total, dtype=torch.int16, device=dev)
+        batch.modulate_batch(t(payload), t(plen), t(np.full(n, bf, np.int32)), t(np.full(n, synth.ts_cycles_for(baud), np.int32)),
+                             t(off), t(ln), total, x, False)
+        stride = ((room + 63) // 64) * 64
+        res = batch.demod_batch(x, t(off), t(ln), np.full(n, bf, np.int32), 14000, out_stride=stride)
+        torch.cuda.synchronize()
+        flat = x.cpu().numpy()
+        want = O.demod_batch(flat, off, ln, np.full(n, bf, np.int32), 14000, out_stride=stride, n_threads=threads)
+        assert_same(res.cpu(), want, f"long outputs, {baud} baud")
+        assert (want["nbytes"] == plen).all(), baud
+        del x, res
+
+
 def test_squelch_stop_at_every_symbol_position_of_a_round(torch_cuda, entry):
     """r5: the squelch test of a data round / pass first asks one question per lane -- is the LARGEST quiet sum of my
     symbols still loud enough? (one zero test on the raw ballot where several lanes share a symbol) -- and only a round

@@ -101,8 +101,9 @@ def main() -> None:
         if eq:
             continue
         h = o.cpu()
+        hp, rp = h.payloads(), ref.payloads()        # (once: a build whose every stream differs must not cost n^2)
         bad = [s_ for s_ in range(n) if any(getattr(h, f)[s_] != getattr(ref, f)[s_] for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"))
-               or h.payloads()[s_] != ref.payloads()[s_]]
+               or hp[s_] != rp[s_]]
         print(f"  {name}: {len(bad)} of {n} streams differ; first: " + "; ".join(
             f"s{s_}: " + ",".join(f"{f}={int(getattr(h, f)[s_])}/{int(getattr(ref, f)[s_])}" for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"))
             for s_ in bad[:4]))
