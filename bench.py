@@ -33,8 +33,8 @@ stderr either: the driver keeps one ~8 KB tail of both streams.
 Timing: a timed region is EXACTLY K steps between two fences (barrier + synchronize on both sides);
 when one region is shorter than --min-region-ms (50 ms) the K-step region is repeated and `value` /
 `ms_per_step` are those of the MEDIAN region (`timed_regions`, `timed_region_ms`).  HIP events inside the
-regions give the per-step median (`event_ms_per_step_median`) and the average launch duration the
-roofline uses (`roofline.kernel_ms`).
+regions give the per-step median (`event_ms_per_step_median`) and the average launch duration of the
+SAME median region, which the roofline uses (`roofline.kernel_ms`).
 
 Launching: `python bench.py --gpus N` with N > 1 from a bare interpreter starts N rank processes
 itself (torch.distributed.run on a free port) BEFORE anything touches the GPU and relays rank 0's
@@ -506,8 +506,13 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
             n_regions = max(1, min(max_regions, int(-(-min_region_ms * 1e-3 // max(elapsed, 1e-6)))))
         r += 1
     elapsed = median(region_s)
+    # The roofline's launch duration comes from the SAME region the value is quoted on -- the one with the median
+    # wall clock -- as the average of its HIP-event time over its K launches (gaps included).  (r5: it used to be the
+    # average over all regions, and one 7 ms hiccup of the box in one of three regions -- value unaffected -- put a
+    # rate of the per-rate table at 0.595 beside a per-launch median of 0.852.)
+    mid = min(range(n_regions), key=lambda k: (abs(region_s[k] - elapsed), k))
     event_ms = sum(region_event_ms)
-    kernel_ms = event_ms / max(steps * n_regions, 1)   # avg launch duration incl. any gaps, all regions
+    kernel_ms = region_event_ms[mid] / max(steps, 1)
 
     # ---- which step gets the full check: a random one among those whose slot still holds it (last region)
     lo = max(0, steps - nslots)
