@@ -95,31 +95,6 @@ __device__ __forceinline__ uint32_t div_exact(uint32_t total, uint32_t n, float 
     return q;
 }
 
-// Output stores (decoded bytes, status words).  AFSK_OUT_POLICY picks the cache policy for A/B builds: 0 plain (shipped),
-// 1 nt, 2 sc0 sc1 (write-through); see profiles/EXPERIMENTS.md, k27.
-#ifndef AFSK_OUT_POLICY
-#define AFSK_OUT_POLICY 0
-#endif
-#if AFSK_OUT_POLICY == 1
-#define AFSK_OUT_BITS " nt"
-#elif AFSK_OUT_POLICY == 2
-#define AFSK_OUT_BITS " sc0 sc1"
-#endif
-__device__ __forceinline__ void out_store_u32(uint32_t* p, uint32_t v) {
-#if AFSK_OUT_POLICY == 0
-    *p = v;
-#else
-    asm volatile("global_store_dword %0, %1, off" AFSK_OUT_BITS :: "v"(p), "v"(v) : "memory");
-#endif
-}
-__device__ __forceinline__ void out_store_u8(uint8_t* p, uint32_t v) {
-#if AFSK_OUT_POLICY == 0
-    *p = (uint8_t)v;
-#else
-    asm volatile("global_store_byte %0, %1, off" AFSK_OUT_BITS :: "v"(p), "v"(v) : "memory");
-#endif
-}
-
 // Limiter ref:287-296 on a packed pair, result biased by 0x8000 per half:
 // x > 512 -> 0xFFFF (32767), x < -512 -> 0x0000 (-32768), else 0x8000 (0).
 __device__ __forceinline__ uint32_t limit_pair_biased(uint32_t x) {
@@ -264,12 +239,12 @@ __device__ __forceinline__ void store_result(const DemodArgs& a, int s, int lane
                                              int32_t n_sym, int bf) {
     if (lane == 0) {
         const int32_t term_sym = st.term_sym >= 0 ? st.term_sym : n_sym;   // ref:362-368
-        out_store_u32(reinterpret_cast<uint32_t*>(a.out_nbytes + s), (uint32_t)st.nbytes);
-        out_store_u32(reinterpret_cast<uint32_t*>(a.out_nbits + s), (uint32_t)st.nbits);
-        out_store_u32(reinterpret_cast<uint32_t*>(a.out_clock_idx + s), (uint32_t)ci);
-        out_store_u32(reinterpret_cast<uint32_t*>(a.out_term_frame + s), (uint32_t)(ci + term_sym * bf));
-        out_store_u32(reinterpret_cast<uint32_t*>(a.out_status + s), st.nbits == 0 ? 2u : 0u);   // ref:422-424
-        if (a.out_corrected) out_store_u32(reinterpret_cast<uint32_t*>(a.out_corrected + s), (uint32_t)st.corrected);
+        a.out_nbytes[s] = st.nbytes;
+        a.out_nbits[s] = st.nbits;
+        a.out_clock_idx[s] = ci;
+        a.out_term_frame[s] = ci + term_sym * bf;
+        a.out_status[s] = st.nbits == 0 ? 2 : 0;   // ref:422-424
+        if (a.out_corrected) a.out_corrected[s] = st.corrected;
     }
 }
 
@@ -302,14 +277,6 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     store_result(a, s, lane, st, ci, n_sym, bf);
 }
 
-// One wave per stream, one block per 4 streams; the hardware dispatcher balances blocks over
-// the CUs (a persistent grid with static striding measured 5 % slower at 65536 streams and
-// no faster at 4096, so it is not used).
-// WPB = waves (= streams) per block; LDS_PER_WAVE >= kFastWaveLdsProduct sets how many blocks fit a
-// CU's 160 KiB LDS, i.e. the number of resident waves per CU.
-// BIG = the kernel for launches of kHintMinStreams or more (compiled WITH the large-launch measures:
-// L2 warming, tail hint); the other instantiation does not even contain their tests -- the extra live
-// scalars cost config #2 1.5 % when both lived in one piece of code.  launch_demod picks the kernel.
 // Which block of streams a workgroup takes (r5).  Workgroups are dealt round-robin over the 8 XCDs (observed, never a
 // contract: a different placement only costs the speed), and every XCD has its own L2 -- with blockIdx.x * WPB the
 // 32 streams whose status words share one 128-byte line of out_nbytes[] ... (and whose output rows are neighbours) are
@@ -329,6 +296,14 @@ __device__ __forceinline__ int xcd_block(int bid, int nwg) {
 #endif
 }
 
+// One wave per stream, one block per 4 streams; the hardware dispatcher balances blocks over
+// the CUs (a persistent grid with static striding measured 5 % slower at 65536 streams and
+// no faster at 4096, so it is not used).
+// WPB = waves (= streams) per block; LDS_PER_WAVE >= kFastWaveLdsProduct sets how many blocks fit a
+// CU's 160 KiB LDS, i.e. the number of resident waves per CU.
+// BIG = the kernel for launches of kHintMinStreams or more (compiled WITH the large-launch measures:
+// L2 warming, tail hint); the other instantiation does not even contain their tests -- the extra live
+// scalars cost config #2 1.5 % when both lived in one piece of code.  launch_demod picks the kernel.
 template <int FLAGS, int WPB = kWavesPerBlock, int LDS_PER_WAVE = 0, bool BIG = false>
 __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     constexpr int kLdsPerWave = LDS_PER_WAVE > 0 ? LDS_PER_WAVE : kFastWaveLdsProduct;

@@ -39,14 +39,13 @@ struct RxDeferred {
     int32_t end_sym;          // first symbol index past the data (valid once st.phase == 2)
     int32_t bytes_done;       // decoded bytes already stored
     int32_t filled;           // symbols parked so far (a multiple of the pass size)
-    int32_t spilled;          // decoded bytes already copied from the LDS output buffer to out_row (rxd_spill)
     uint64_t cur;             // bits of the 64-symbol word being filled
 };
 
 __device__ __forceinline__ void rxd_init(RxDeferred& d) {
     d.st.phase = 0; d.st.hist = 0; d.st.nbits = 0; d.st.nbytes = 0; d.st.term_sym = -1;
     d.st.pend = 0; d.st.npend = 0; d.st.corrected = 0;
-    d.end_sym = 0; d.bytes_done = 0; d.filled = 0; d.spilled = 0; d.cur = 0;
+    d.end_sym = 0; d.bytes_done = 0; d.filled = 0; d.cur = 0;
 }
 
 // squelch stop inside a pass whose data symbols start at `start` (ref:372-376)
@@ -103,52 +102,7 @@ __device__ __forceinline__ uint32_t hamming_byte(uint32_t c, uint32_t& pos2) {
     return (hi << 4) | lo;                                                      // ref:393-399: first nibble high
 }
 
-// The output buffer of the wave (kOutBufOffset; `words` points at the bit buffer of the same LDS block).
-__device__ __forceinline__ uint8_t* rxd_outbuf(unsigned long long* words) {
-    return reinterpret_cast<uint8_t*>(words) + (kOutBufOffset - kBitBufOffset);
-}
-
-// bytes [d.spilled, upto) of the stream leave the LDS output buffer (byte j at offset j - d.spilled): at the end of the
-// stream, where a store delays nothing, or when the buffer is full
-__device__ __forceinline__ void rxd_spill(RxDeferred& d, int upto, int lane, unsigned long long* words,
-                                          uint8_t* out_row, int out_stride) {
-    if (upto <= d.spilled) return;
-    const uint8_t* obuf = rxd_outbuf(words);
-    wave_lds_sync();                  // the bytes were written by other lanes
-    const int lim = upto < out_stride ? upto : out_stride;       // bytes [d.spilled, lim) go out
-    int j1 = d.spilled;                                          // ... [d.spilled, j1) as dwords
-#ifndef AFSK_SPILL_BYTES
-    // One dword per lane where the row allows it (a 4-byte-aligned position: every row of a result whose stride is a
-    // multiple of 4, e.g. batch.out_stride_for's): a quarter of the store requests of the byte form.
-    if (((reinterpret_cast<uintptr_t>(out_row) + (uintptr_t)(uint32_t)d.spilled) & 3u) == 0 && lim - d.spilled >= 4) {
-        const int ndw = (lim - d.spilled) >> 2;
-        for (int k0 = 0; k0 < ndw; k0 += 64) {
-            const int k = k0 + lane;
-            if (k < ndw)
-                out_store_u32(reinterpret_cast<uint32_t*>(out_row + d.spilled + 4 * k), *reinterpret_cast<const uint32_t*>(obuf + 4 * k));
-        }
-        j1 = d.spilled + 4 * ndw;
-    }
-#endif
-    for (int j0 = j1; j0 < lim; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < lim) out_store_u8(out_row + j, obuf[j - d.spilled]);
-    }
-    wave_lds_sync();                  // later bytes overwrite the buffer from offset 0
-    d.spilled = upto;
-}
-
-// A round that ran on part of its symbols and has to run again (tail hint, holding_wait) goes back to the saved
-// receiver state -- except for what has left the output buffer meanwhile: those bytes are final (the decoded prefix
-// does not depend on how many symbols of the round were there) and the buffer has been reused from offset 0.
-__device__ __forceinline__ void rxd_restore(RxDeferred& d, const RxDeferred& saved) {
-    const int32_t spilled = d.spilled;
-    d = saved;
-    d.spilled = spilled;
-    if (d.bytes_done < spilled) d.bytes_done = spilled;   // (cannot happen: a mid-stream batch is < 128 bytes, the buffer 1 KiB; keeps the buffer index non-negative)
-}
-
-// decode every byte whose 14 coded bits lie below symbol index `avail` into the output buffer
+// decode and store every byte whose 14 coded bits lie below symbol index `avail`
 template <int PS>
 __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
                                           unsigned long long* words, uint8_t* out_row, int out_stride) {
@@ -160,9 +114,7 @@ __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
     }
     wave_lds_sync();                  // lane 0 stored the words, every lane reads them
     const uint32_t* dwords = reinterpret_cast<const uint32_t*>(words);          // the bit buffer as 128 dwords
-    uint8_t* obuf = rxd_outbuf(words);
     for (int j0 = d.bytes_done; j0 < jnew; j0 += 64) {
-        if (j0 + 64 - d.spilled > kOutBufBytes) rxd_spill(d, j0, lane, words, out_row, out_stride);   // (once per KiB of output)
         const int j = j0 + lane;
         bool fix0 = false, fix1 = false;       // soft output: non-zero syndromes (ref:147)
         if (j < jnew) {
@@ -173,7 +125,7 @@ __device__ __forceinline__ void rxd_flush(RxDeferred& d, int avail, int lane,
             const uint32_t c = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)g & 31u) & 0x3FFFu;
             uint32_t pos2;
             const uint32_t byte = hamming_byte(c, pos2);
-            obuf[j - d.spilled] = (uint8_t)byte;
+            if (j < out_stride) out_row[j] = (uint8_t)byte;
             fix0 = (pos2 & 7u) != 0;
             fix1 = (pos2 >> 7) != 0;
         }
@@ -345,9 +297,7 @@ __device__ __forceinline__ void rxd_round(RxDeferred& d, const uint64_t (&B)[SPL
     if (rxd_flush_due(d, k0 + nv)) rxd_flush<64>(d, k0 + nv, lane, words, out_row, out_stride);
 }
 
-// end of stream: K symbols were examined unless the squelch stopped earlier.  The last bytes stay in the LDS output
-// buffer: the caller drains the ring requests still in flight (vmcnt(0): the LDS block is about to be released), THEN
-// calls rxd_spill -- the wave ends without waiting for the acknowledgement of its stores.
+// end of stream: K symbols were examined unless the squelch stopped earlier
 template <int PS>
 __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, unsigned long long* words,
                                            uint8_t* out_row, int out_stride) {
@@ -356,9 +306,6 @@ __device__ __forceinline__ void rxd_finish(RxDeferred& d, int32_t K, int lane, u
     d.st.nbits = end > d.st.term_sym ? end - d.st.term_sym : 0;
     d.st.nbytes = d.st.nbits / 14;
     rxd_flush<PS>(d, end, lane, words, out_row, out_stride);
-#ifdef AFSK_SPILL_BEFORE_DRAIN
-    rxd_spill(d, d.bytes_done, lane, words, out_row, out_stride);
-#endif
     if ((d.st.nbits / 7) & 1) {       // ECC.decode also corrects an odd last codeword (ref:157-162)
         if constexpr (PS != 64) {
             if ((d.filled & 63) != 0 && lane == 0) words[(d.filled >> 6) & (kBitWords - 1)] = d.cur;

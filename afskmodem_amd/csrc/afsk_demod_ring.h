@@ -317,12 +317,7 @@ struct FastRing {
 };
 
 // ------------------------------------------------------------------ phase A (fast)
-// Decoded bytes wait here for the end of the stream (r5): a store issued in the middle of a stream sits in the same
-// in-order vmcnt chain as the ring requests, and two or three rounds later every wait of the round loop waits for its
-// acknowledgement too.  1 KiB = the output of 14336 symbols; longer outputs are spilled every KiB (rxd_spill).
-constexpr int kOutBufOffset = kHintStashOffset + 16;
-constexpr int kOutBufBytes = 1024;
-constexpr int kFastWaveLdsProduct = kOutBufOffset + kOutBufBytes;   // 19,472 B of LDS per wave
+constexpr int kFastWaveLdsProduct = kHintStashOffset + 16;      // 18,448 B of LDS per wave
 
 // ---- register re-alignment helpers (phase A sub-windows, phase B pieces) ----
 // Re-align 24 dwords (six aligned 16-byte reads) by S bytes into 20 dwords.

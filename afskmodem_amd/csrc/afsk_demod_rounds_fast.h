@@ -210,7 +210,7 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
                                       margins, mstride);
         if (rd.st.phase == 2) break;
         if (HINTED && partial) {           // no squelch stop among the symbols that were there: fetch the rest, run the round again
-            rxd_restore(rd, saved);
+            rd = saved;
             fr.template fetch_through<(FLAGS & 4) ? 0 : 2>(last >> 10);
             r--;
         }

@@ -302,9 +302,6 @@ __device__ __forceinline__ void demod_stream_rt(const int16_t* xs, int32_t len, 
     rxd_finish<32>(rd, K, lane, words, out_row, out_stride);
     st = rd.st;
     wait_vmcnt<0>();   // drain DMA still in flight before the LDS region is released
-#ifndef AFSK_SPILL_BEFORE_DRAIN
-    rxd_spill(rd, rd.bytes_done, lane, words, out_row, out_stride);   // (behind the drain: nothing waits for these stores)
-#endif
 }
 
 }  // namespace afsk

@@ -1013,11 +1013,12 @@ def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_
         assert (want["nbytes"] > 0).sum() > n // 2
 
 
-def test_output_buffer_spills_with_the_tail_hint_armed(torch_cuda, entry):
-    """r5: decoded bytes wait in a 1 KiB LDS buffer for the end of the stream and are spilled whenever it is full.
-    Launches large enough to arm the tail hint (partial rounds that run twice: the receiver state goes back, the
-    spilled prefix does not) of streams whose output is longer than the buffer -- 1.1 to 3.3 KiB -- with payload
-    lengths that move the signal end through the rounds and the buffer boundary through the flush batches."""
+def test_long_outputs_with_the_tail_hint_armed(torch_cuda, entry):
+    """Launches large enough to arm the tail hint (partial rounds that run twice: the receiver state goes back and the
+    deferred Hamming flushes of the round are repeated) of streams that decode to 1.0 - 1.5 KiB each -- sixteen to
+    twenty-four 64-byte flushes per stream, the bit buffer wrapping several times -- with payload lengths that move
+    the signal end through the rounds and through the flush batches.  (r5; it also pinned the LDS output buffer that
+    was measured and dropped: profiles/EXPERIMENTS.md, k22 / k23.)"""
     import os
     torch = torch_cuda
     dev = "cuda:0"
