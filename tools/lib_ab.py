@@ -33,6 +33,7 @@ def main() -> None:
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--order", default="rotate", choices=["fixed", "rotate"])
+    ap.add_argument("--stride-align", type=int, default=0, help="round the output row stride up to a multiple of this (0: bench.py's)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -45,6 +46,8 @@ def main() -> None:
     ctx = bench.Ctx(args)
     sh = bench.Shard(ctx, "custom", a.streams)
     n, stride = sh.n_local, sh.stride
+    if a.stride_align > 0:
+        stride = -(-stride // a.stride_align) * a.stride_align
     sptr = C.c_void_p(ctx.cur.cuda_stream)
     libs, calls, outs = [], [], []
     for path in a.libs:
@@ -119,7 +122,7 @@ def main() -> None:
             t = run(i, a.reps)
             if r > 0:
                 times[i].append(t)
-    print(f"bauds {a.bauds} streams {n} entry {fn.__name__} round trip {ok_payload:.4f}")
+    print(f"bauds {a.bauds} streams {n} entry {fn.__name__} out_stride {stride} round trip {ok_payload:.4f}")
     base = None
     for name, ts, eq in zip(libs, times, same):
         ts.sort()
