@@ -60,8 +60,15 @@ def threshold_gt(t) -> int:
 
 
 def out_stride_for(max_len: int, min_bit_frames: int) -> int:
-    """Bytes per output row that can never truncate: one byte per 14 symbols."""
-    return int(max_len // (14 * max(min_bit_frames, 4)) + 2 + 3) & ~3
+    """Bytes per output row that can never truncate: one byte per 14 symbols (a multiple of 4).
+
+    Rows longer than 192 bytes are rounded up to whole 128-byte cache lines (r5): in an allocation that starts on a
+    line -- torch's do -- every row then starts on a line of its own and dirties ceil(nbytes / 128) of them instead
+    of one more on average, and the number of dirty lines that leave the L2s is what the output of a launch costs
+    (12000 baud -1.5 %, 6000 / 4000 / 3000 baud -0.5 ... -0.8 %: profiles/r5_exp31_row_alignment.txt).
+    Short rows stay packed: several of them share a line, and neighbouring streams meet in one L2."""
+    s = int(max_len // (14 * max(min_bit_frames, 4)) + 2 + 3) & ~3
+    return s if s <= 192 else (s + 127) & ~127
 
 
 # ----------------------------------------------------------------- host arrays

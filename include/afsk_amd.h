@@ -82,7 +82,11 @@ int afsk_sync(void *hip_stream);
  *                 must be a multiple of 4 with 2*bit_frames < 4096
  *  amp_end_threshold  Receiver(amp_end_threshold=...) (:276), squelch of :375
  *  out_bytes      [n, out_stride] decoded payload bytes (row s, first
- *                 min(out_nbytes[s], out_stride) bytes are written)
+ *                 min(out_nbytes[s], out_stride) bytes are written; any
+ *                 stride works -- rows of more than ~200 bytes are cheapest
+ *                 when out_bytes and out_stride are multiples of 128: what a
+ *                 launch pays for its output is the number of cache lines
+ *                 it dirties)
  *  out_nbytes     [n] number of decoded bytes (may exceed out_stride: the row
  *                 was then truncated; size rows as stream_len/(14*bf)+1)
  *  out_nbits      [n] coded bits demodulated incl. ECC (debug line :380)
