@@ -277,25 +277,6 @@ __device__ __forceinline__ void process_stream(const DemodArgs& a, int s, int64_
     store_result(a, s, lane, st, ci, n_sym, bf);
 }
 
-// Which block of streams a workgroup takes (r5).  Workgroups are dealt round-robin over the 8 XCDs (observed, never a
-// contract: a different placement only costs the speed), and every XCD has its own L2 -- with blockIdx.x * WPB the
-// 32 streams whose status words share one 128-byte line of out_nbytes[] ... (and whose output rows are neighbours) are
-// written by 8 blocks on 8 different XCDs: every 4- or 54-byte store leaves its L2 as a partial line of its own, and
-// small writes threaded into a streaming read cost the memory system far more than their bytes (4 - 10 % of the
-// kernel for 0.1 - 0.5 % of the traffic: profiles/r5_exp24_store_forms.txt).  Inside every group of 64 consecutive
-// blocks the 8 blocks of one XCD (equal blockIdx % 8, dispatched together) take 8 CONSECUTIVE blocks of streams -- one
-// line of every status array, 32 neighbouring rows -- so their stores meet in one L2 and leave it merged.  The launch
-// as a whole still walks the input front to back (handing every XCD one contiguous eighth of the streams was 1 - 6 %
-// SLOWER: profiles/r5_exp25_xcd_remap.txt).  A permutation of [0, nwg): identity in the last, partial group.
-__device__ __forceinline__ int xcd_block(int bid, int nwg) {
-#ifdef AFSK_NO_XCD_REMAP
-    return bid;
-#else
-    if (bid >= (nwg & ~63)) return bid;
-    return (bid & ~63) | ((bid & 7) << 3) | ((bid >> 3) & 7);
-#endif
-}
-
 // One wave per stream, one block per 4 streams; the hardware dispatcher balances blocks over
 // the CUs (a persistent grid with static striding measured 5 % slower at 65536 streams and
 // no faster at 4096, so it is not used).

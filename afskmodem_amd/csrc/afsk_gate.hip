@@ -21,7 +21,9 @@ typedef uint32_t vec16 __attribute__((ext_vector_type(4), aligned(2)));
 
 __global__ __launch_bounds__(256) void block_amp_kernel(GateArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave = block slot
+    // (xcd_block: the 32 amplitudes of one 128-byte line are written by 8 workgroups -- let them sit on ONE XCD, so that
+    // the line leaves its L2 once, whole: afsk_kernels.h)
+    const int64_t w = (int64_t)xcd_block((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);   // global wave = block slot
     const int s = (int)(w / a.max_blocks);
     if (s >= a.n_streams) return;
     const int b = (int)(w - (int64_t)s * a.max_blocks);

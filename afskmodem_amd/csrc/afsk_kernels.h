@@ -5,6 +5,25 @@
 
 namespace afsk {
 
+// Which block of work a workgroup takes (r5; demod kernels: 4 streams, block_amp_kernel: 4 listen blocks).  Workgroups are dealt round-robin over the 8 XCDs (observed, never a
+// contract: a different placement only costs the speed), and every XCD has its own L2 -- with blockIdx.x * WPB the
+// 32 streams whose status words share one 128-byte line of out_nbytes[] ... (and whose output rows are neighbours) are
+// written by 8 blocks on 8 different XCDs: every 4- or 54-byte store leaves its L2 as a partial line of its own, and
+// small writes threaded into a streaming read cost the memory system far more than their bytes (4 - 10 % of the
+// kernel for 0.1 - 0.5 % of the traffic: profiles/r5_exp24_store_forms.txt).  Inside every group of 64 consecutive
+// blocks the 8 blocks of one XCD (equal blockIdx % 8, dispatched together) take 8 CONSECUTIVE blocks of streams -- one
+// line of every status array, 32 neighbouring rows -- so their stores meet in one L2 and leave it merged.  The launch
+// as a whole still walks the input front to back (handing every XCD one contiguous eighth of the streams was 1 - 6 %
+// SLOWER: profiles/r5_exp25_xcd_remap.txt).  A permutation of [0, nwg): identity in the last, partial group.
+__device__ __forceinline__ int xcd_block(int bid, int nwg) {
+#ifdef AFSK_NO_XCD_REMAP
+    return bid;
+#else
+    if (bid >= (nwg & ~63)) return bid;
+    return (bid & ~63) | ((bid & 7) << 3) | ((bid >> 3) & 7);
+#endif
+}
+
 struct DemodArgs {
     const int16_t* samples;
     const int64_t* stream_offset;
