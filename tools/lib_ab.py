@@ -33,6 +33,7 @@ def main() -> None:
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--order", default="rotate", choices=["fixed", "rotate"])
+    ap.add_argument("--rate-order", default="cycle", choices=["cycle", "blocks"], help="how --bauds are laid over the streams (bench.py --rate-order)")
     ap.add_argument("--stride-align", type=int, default=0, help="round the output row stride up to a multiple of this (0: bench.py's)")
     a = ap.parse_args()
     import numpy as np
@@ -40,6 +41,7 @@ def main() -> None:
     from afskmodem_amd import _native, batch
     bauds = tuple(int(b) for b in a.bauds.split(","))
     bench.WORKLOADS["custom"] = (a.streams, bauds, None, f"custom {bauds}")
+    bench.RATE_ORDER = a.rate_order
     args = types.SimpleNamespace(gpus=1, share_gpu0=False, force_gather=False, dist_backend="nccl", entry=a.entry,
                                  pg_timeout_s=90.0)
     os.environ.setdefault("AFSK_BENCH_VERBOSE", "0")
