@@ -63,11 +63,6 @@ SIGNATURES = {
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p]),
-    "afsk_group_scratch_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
-    "afsk_demod_batch_grouped_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "afsk_demod_batch_host": (C.c_int, [_i16p, C.c_int64, _i64p, _i32p, _i32p, C.c_int32,
                                         C.c_int32, _u8p, C.c_int32, _i32p, _i32p, _i32p, _i32p,
                                         _i32p]),

@@ -328,19 +328,6 @@ class GroupPlan:
         _native.check(lib.afsk_group_plan_info(self.handle, None, None, bf, cnt, ng.value))
         return [(int(bf[k]), int(cnt[k])) for k in range(ng.value)]
 
-    def scratch_bytes(self, out_stride: int) -> int:
-        """Device scratch ``afsk_demod_batch_grouped_staged`` wants for rows of ``out_stride`` bytes (0: this plan
-        never stages -- fewer than four rates -- or the stride is not a multiple of 4)."""
-        out_stride = int(out_stride)
-        if out_stride < 4 or out_stride % 4:
-            return 0
-        cache = self.__dict__.setdefault("_scratch_bytes", {})
-        if out_stride not in cache:
-            b = C.c_int64()
-            _native.check(_native.lib().afsk_group_scratch_bytes(self.handle, out_stride, C.byref(b)))
-            cache[out_stride] = int(b.value)
-        return cache[out_stride]
-
     def close(self) -> None:
         """Free the plan (after the launches that use it have completed)."""
         if self._h:
@@ -451,25 +438,11 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         if grouped:
             if plan is None:
                 plan = _cached_plan(bit_frames, n, dev)
-            # four or more rates: results in walk order into scratch, then the permuting copy (afsk_amd.h); the scratch
-            # is this call's own (torch's caching allocator: a block per launch in flight), released in stream order
-            need = plan.scratch_bytes(stride) if not diagnostics else 0
-            if need > 0:
-                scratch = torch.empty(need, dtype=torch.uint8, device=dev)
-                if isinstance(stream, torch.cuda.Stream):
-                    scratch.record_stream(stream)
-                _native.check(lib.afsk_demod_batch_grouped_staged(
-                    plan.handle, samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
-                    threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-                    out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-                    out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, scratch.data_ptr(), need,
-                    _stream_ptr(stream, dev)))
-            else:
-                _native.check(lib.afsk_demod_batch_grouped(
-                    plan.handle, samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
-                    threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
-                    out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
-                    out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
+            _native.check(lib.afsk_demod_batch_grouped(
+                plan.handle, samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
+                threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),
+                out.nbits.data_ptr(), out.clock_idx.data_ptr(), out.term_frame.data_ptr(),
+                out.status.data_ptr(), corrected_ptr, margins_ptr, mstride, _stream_ptr(stream, dev)))
             out._plan_keepalive = plan  # type: ignore[attr-defined]   (the plan's device index list outlives the launch)
             return out
         bf = _as_device_i32(bit_frames, n, dev)

@@ -602,7 +602,6 @@ struct GroupPlan {
     std::vector<int32_t> h_upload;               // [n] index list (bucket after bucket) + [n] bit_frames by stream number
     int32_t* d_index = nullptr;                  // [n] the permutation; followed, in the same storage, by
     int32_t* d_bf = nullptr;                     // [n] bit_frames by stream number (the kernel's per-stream switch reads it)
-    int32_t* d_inv = nullptr;                    // [n] list position of every stream (plans with storage of their own: the staged launch)
     bool own_index = false;
 
     ~GroupPlan() {
@@ -630,10 +629,9 @@ struct GroupPlan {
             cursor[(size_t)bf] = first;
             first += count[(size_t)bf];
         }
-        h_upload.resize(3 * (size_t)n);
+        h_upload.resize(2 * (size_t)n);
         for (int32_t s = 0; s < n; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
         if (n > 0) std::memcpy(h_upload.data() + n, h_bf, (size_t)n * 4);
-        for (int32_t w = 0; w < n; w++) h_upload[2 * (size_t)n + (size_t)h_upload[(size_t)w]] = w;   // inverse of the list
     }
 
     // device part: index list + bit_frames either in storage the caller provides (2 n int32, copied
@@ -647,49 +645,11 @@ struct GroupPlan {
             d_bf = d_index + n;
             return hipMemcpyAsync(d_index, h_upload.data(), (size_t)n * 8, hipMemcpyHostToDevice, copy_stream);
         }
-        e = hipMalloc((void**)&d_index, (size_t)n * 12);
+        e = hipMalloc((void**)&d_index, (size_t)n * 8);
         if (e != hipSuccess) { d_index = nullptr; return e; }
         d_bf = d_index + n;
-        d_inv = d_index + 2 * (size_t)n;
         own_index = true;
-        return hipMemcpy(d_index, h_upload.data(), (size_t)n * 12, hipMemcpyHostToDevice);
-    }
-
-    // ---- staged launch (afsk_demod_batch_grouped_staged): results in LIST order into the caller's scratch, then one
-    // permuting copy.  A rate-sorted walk that writes at the stream numbers touches every 128-byte line of the results
-    // once per rate (the 32 status words of a line, neighbouring rows), and every one of those partial lines costs the
-    // memory system as much as a whole one: 2.6 % of the launch for four cycling rates, 5 % for eighteen.
-    static size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
-    size_t scratch_bytes(int32_t stride) const { return pad16((size_t)n * (size_t)stride) + 6 * pad16((size_t)n * 4); }
-    bool can_stage(const afsk::DemodArgs& a, const void* scratch, int64_t bytes) const {
-        return sorted() && d_inv && !a.out_margins && a.out_stride >= 4 && (a.out_stride & 3) == 0 && scratch &&
-               (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out_bytes) & 3) == 0 &&
-               bytes >= 0 && (size_t)bytes >= scratch_bytes(a.out_stride);
-    }
-    hipError_t launch_staged(afsk::DemodArgs a, void* scratch, hipStream_t stream) const {
-        uint8_t* p = static_cast<uint8_t*>(scratch);
-        afsk::PermuteArgs q;
-        q.inv = d_inv; q.n = n; q.stride = a.out_stride;
-        q.out_bytes = a.out_bytes; q.out_nbytes = a.out_nbytes; q.out_nbits = a.out_nbits; q.out_clock_idx = a.out_clock_idx;
-        q.out_term_frame = a.out_term_frame; q.out_status = a.out_status; q.out_corrected = a.out_corrected;
-        const size_t words = pad16((size_t)n * 4);
-        uint8_t* w0 = p + pad16((size_t)n * (size_t)a.out_stride);
-        a.out_bytes = p;
-        a.out_nbytes = reinterpret_cast<int32_t*>(w0);
-        a.out_nbits = reinterpret_cast<int32_t*>(w0 + words);
-        a.out_clock_idx = reinterpret_cast<int32_t*>(w0 + 2 * words);
-        a.out_term_frame = reinterpret_cast<int32_t*>(w0 + 3 * words);
-        a.out_status = reinterpret_cast<int32_t*>(w0 + 4 * words);
-        a.out_corrected = a.out_corrected ? reinterpret_cast<int32_t*>(w0 + 5 * words) : nullptr;
-        q.st_bytes = a.out_bytes; q.st_nbytes = a.out_nbytes; q.st_nbits = a.out_nbits; q.st_clock_idx = a.out_clock_idx;
-        q.st_term_frame = a.out_term_frame; q.st_status = a.out_status; q.st_corrected = a.out_corrected;
-        a.n_streams = n;
-        a.bit_frames = d_bf;
-        a.stream_index = d_index;
-        a.out_by_list = 1;
-        hipError_t e = afsk::launch_demod(a, stream);
-        if (e != hipSuccess) return e;
-        return afsk::launch_permute_results(q, stream);
+        return hipMemcpy(d_index, h_upload.data(), (size_t)n * 8, hipMemcpyHostToDevice);
     }
 
     // ONE launch: the uniform kernel when the whole batch is one valid rate, else the per-stream kernel
@@ -889,46 +849,6 @@ int afsk_demod_batch_grouped(const afsk_group_plan* plan, const int16_t* samples
     a.margin_stride = margin_stride;
     hipError_t e = plan->p.launch(a, (hipStream_t)hip_stream);
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel (grouped)");
-}
-
-int afsk_group_scratch_bytes(const afsk_group_plan* plan, int32_t out_stride, int64_t* out_bytes) {
-    if (!plan || !out_bytes) return fail(AFSK_E_INVALID_ARG, "null pointer argument");
-    if (out_stride < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
-    *out_bytes = plan->p.sorted() ? (int64_t)plan->p.scratch_bytes(out_stride) : 0;   // 0: this plan never stages
-    return AFSK_OK;
-}
-
-int afsk_demod_batch_grouped_staged(const afsk_group_plan* plan, const int16_t* samples,
-                                    const int64_t* stream_offset, const int32_t* stream_len,
-                                    int32_t amp_end_threshold, uint8_t* out_bytes, int32_t out_stride,
-                                    int32_t* out_nbytes, int32_t* out_nbits, int32_t* out_clock_idx,
-                                    int32_t* out_term_frame, int32_t* out_status, int32_t* out_corrected,
-                                    int32_t* out_margins, int32_t margin_stride, void* scratch, int64_t scratch_bytes,
-                                    void* hip_stream) {
-    if (!plan) return fail(AFSK_E_INVALID_ARG, "null plan");
-    if (out_stride < 0 || margin_stride < 0 || scratch_bytes < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
-    if (plan->p.n == 0) return AFSK_OK;
-    if (!samples || !stream_offset || !stream_len || !out_nbytes || !out_nbits ||
-        !out_clock_idx || !out_term_frame || !out_status || (!out_bytes && out_stride > 0))
-        return fail(AFSK_E_INVALID_ARG, "null pointer argument");
-    if (int rc = require_device()) return rc;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev != plan->p.device)
-        return fail(AFSK_E_INVALID_ARG, "the plan was created on another device than the current one");
-    afsk::DemodArgs a;
-    a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
-    a.amp_end = amp_end_threshold;
-    a.out_bytes = out_bytes; a.out_stride = out_stride; a.out_nbytes = out_nbytes;
-    a.out_nbits = out_nbits; a.out_clock_idx = out_clock_idx; a.out_term_frame = out_term_frame;
-    a.out_status = out_status;
-    a.out_corrected = out_corrected;
-    a.out_margins = margin_stride > 0 ? out_margins : nullptr;
-    a.margin_stride = margin_stride;
-    // (anything the staged form does not cover -- fewer than four rates, soft margins, a stride that is not a
-    // multiple of 4, scratch too small or absent -- is the plain grouped launch: same results)
-    hipError_t e = plan->p.can_stage(a, scratch, scratch_bytes) ? plan->p.launch_staged(a, scratch, (hipStream_t)hip_stream)
-                                                                : plan->p.launch(a, (hipStream_t)hip_stream);
-    return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch demod_kernel (grouped, staged)");
 }
 
 // The host entries see the bit_frames array: one value for all streams -> the uniform kernel;

@@ -40,59 +40,4 @@ hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream) {
     }
 }
 
-// ---- results in list order -> stream order (grouped dispatch, staged form) ----------------------------------------
-// One workgroup per 32 consecutive streams of the OUTPUT: their status words are one 128-byte line per array and their
-// rows are neighbours, so everything this kernel writes leaves the L2 as whole, merged lines -- which is the point: a
-// rate-sorted walk writing at the stream numbers itself touches every line once per rate, minutes of kernel time apart
-// in cache terms (profiles/r5_exp35_rate_order_and_partial_lines.txt).
-constexpr int kPermuteStreams = 32;
-
-__global__ __launch_bounds__(256) void permute_results_kernel(PermuteArgs a) {
-    __shared__ int32_t pos[kPermuteStreams];
-    __shared__ int32_t nbs[kPermuteStreams];
-    const int t = (int)threadIdx.x;
-    const int s0 = (int)blockIdx.x * kPermuteStreams;
-    if (t < kPermuteStreams) {
-        const int s = s0 + t;
-        int32_t w = 0, nb = 0;
-        if (s < a.n) {
-            w = a.inv[s];
-            const int32_t nbytes = a.st_nbytes[w];
-            a.out_nbytes[s] = nbytes;
-            a.out_nbits[s] = a.st_nbits[w];
-            a.out_clock_idx[s] = a.st_clock_idx[w];
-            a.out_term_frame[s] = a.st_term_frame[w];
-            a.out_status[s] = a.st_status[w];
-            if (a.out_corrected) a.out_corrected[s] = a.st_corrected[w];
-            nb = nbytes < 0 ? 0 : (nbytes < a.stride ? nbytes : a.stride);
-        }
-        pos[t] = w;
-        nbs[t] = nb;
-    }
-    __syncthreads();
-    const int dw_per_row = a.stride >> 2;
-    const int total = kPermuteStreams * dw_per_row;
-    for (int idx = t; idx < total; idx += 256) {
-        const int r = idx / dw_per_row;
-        const int j = 4 * (idx - r * dw_per_row);
-        const int s = s0 + r;
-        if (s >= a.n) break;
-        const int nb = nbs[r];
-        if (j >= nb) continue;
-        const uint8_t* src = a.st_bytes + (int64_t)pos[r] * a.stride + j;
-        uint8_t* dst = a.out_bytes + (int64_t)s * a.stride + j;
-        if (j + 4 <= nb) {
-            *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
-        } else {
-            for (int k = 0; k < nb - j; k++) dst[k] = src[k];
-        }
-    }
-}
-
-hipError_t launch_permute_results(const PermuteArgs& a, hipStream_t stream) {
-    if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(permute_results_kernel, dim3((uint32_t)((a.n + kPermuteStreams - 1) / kPermuteStreams)), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-
 }  // namespace afsk

@@ -300,9 +300,7 @@ __global__ __launch_bounds__(64 * WPB) void demod_kernel_t(DemodArgs a) {
     if constexpr (FLAGS & 64) {   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime)
         if (lane == 0) a.debug_stamps[4 * s + 0] = __builtin_amdgcn_s_memrealtime();
     }
-    // (process_stream takes the index of its OUTPUTS: the stream number, or the list position when a permuting copy follows)
-    const int so = (a.stream_index && a.out_by_list) ? w : s;
-    process_stream<FLAGS, BIG>(a, so, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
+    process_stream<FLAGS, BIG>(a, s, a.stream_offset[s], a.stream_len[s], a.bit_frames[s],
                                lds_all + wave * kLdsPerWave, lane);
     if constexpr (FLAGS & 64) {
         if (lane == 0) a.debug_stamps[4 * s + 3] = __builtin_amdgcn_s_memrealtime();

@@ -48,10 +48,6 @@ struct DemodArgs {
     // (the rate-sorted list of all n_streams); every per-stream array, inputs and outputs, is addressed by that
     // stream number.  null = wave w decodes stream w.
     const int32_t* stream_index = nullptr;
-    // out_by_list != 0 (with stream_index): wave w writes its results at index w -- LIST order -- instead of at its
-    // stream number; a permuting copy (launch_permute_results) then puts them where the C-ABI wants them.  A
-    // rate-sorted walk that writes at the stream numbers touches every 128-byte line of the results once per rate.
-    int32_t out_by_list = 0;
 };
 
 // Longest stream the kernels address (32-bit byte offsets into a stream): AFSK_MAX_STREAM_LEN of the C-ABI.
@@ -103,22 +99,6 @@ struct GateArgs {
 
 hipError_t launch_gate(const GateArgs& a, hipStream_t stream);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t stream);
-
-// Results of a launch that wrote in LIST order (DemodArgs::out_by_list) -> where the C-ABI wants them: stream s takes
-// what list position inv[s] holds.  Rows: the first min(nbytes, stride) bytes only (the rest of a caller's row is
-// never touched); stride a multiple of 4, both byte arrays 4-byte aligned.
-struct PermuteArgs {
-    const int32_t* inv;            // [n] list position of stream s
-    int32_t n;
-    int32_t stride;
-    const uint8_t* st_bytes;       // staged results, list order
-    const int32_t* st_nbytes; const int32_t* st_nbits; const int32_t* st_clock_idx;
-    const int32_t* st_term_frame; const int32_t* st_status; const int32_t* st_corrected;   // (st_corrected / out_corrected may be null)
-    uint8_t* out_bytes;
-    int32_t* out_nbytes; int32_t* out_nbits; int32_t* out_clock_idx;
-    int32_t* out_term_frame; int32_t* out_status; int32_t* out_corrected;
-};
-hipError_t launch_permute_results(const PermuteArgs& a, hipStream_t stream);
 // one bit_frames (a.uniform_bit_frames, host-validated) for every stream of the launch
 hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t stream);
 hipError_t launch_modulate(ModulateArgs a, int32_t max_len, hipStream_t stream);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AFSK_ABI_VERSION 3 /* 2: afsk_group_plan_* / afsk_demod_batch_grouped, AFSK_ST_BAD_LENGTH, afsk_wav_egress; 3: afsk_demod_batch_grouped_staged */
+#define AFSK_ABI_VERSION 2 /* 2: afsk_group_plan_* / afsk_demod_batch_grouped, AFSK_ST_BAD_LENGTH, afsk_wav_egress */
 
 /* return codes */
 #define AFSK_OK 0
@@ -159,7 +159,7 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
  * stays the entry for rates only the device knows.
  * (One launch of the uniform kernel per rate on forked HIP streams was measured and rejected: DESIGN.md 4.4.)
  *
- *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates 12 n bytes on the current device and
+ *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates 8 n bytes on the current device and
  *                           fills them (synchronous).
  *  afsk_group_plan_info     n_streams, number of buckets, and per bucket (first `cap` of them, in launch
  *                           order: largest first) its bit_frames (0 = the refused streams) and stream count;
@@ -179,29 +179,6 @@ int afsk_demod_batch_grouped(const afsk_group_plan *plan, const int16_t *samples
                              int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
                              int32_t *out_term_frame, int32_t *out_status, int32_t *out_corrected,
                              int32_t *out_margins, int32_t margin_stride, void *hip_stream);
-
-/*
- * afsk_demod_batch_grouped with device scratch of the caller's (ABI 3).  A rate-sorted walk that writes its results at
- * the original stream numbers touches every 128-byte line of the outputs once per rate -- the 32 status words of a
- * line, neighbouring rows -- and a partly written line costs the memory system what a whole one does: 2.6 % of the
- * launch for four rates cycling over the streams, 5 % for eighteen.  With scratch the kernel writes its results in
- * WALK order (whole, merged lines) and a second, small kernel on the same stream copies them to the stream numbers
- * (one workgroup per 32 streams of the output: whole lines again).  Same outputs, bit for bit, and like there only
- * the first min(out_nbytes[s], out_stride) bytes of a row are written.  Still nothing but kernel launches
- * (asynchronous, capture-safe, plans may be shared) -- the scratch is the caller's: at least
- * afsk_group_scratch_bytes(plan, out_stride) bytes of device memory, 16-byte aligned, not used by anything else
- * until the launch has completed (one scratch per launch in flight).  Whenever the staged form does not apply --
- * fewer than four rates (afsk_group_scratch_bytes reports 0), out_margins wanted, out_stride not a multiple of 4 or
- * out_bytes not 4-byte aligned, scratch NULL / too small -- the call IS afsk_demod_batch_grouped.
- */
-int afsk_group_scratch_bytes(const afsk_group_plan *plan, int32_t out_stride, int64_t *out_bytes);
-int afsk_demod_batch_grouped_staged(const afsk_group_plan *plan, const int16_t *samples,
-                                    const int64_t *stream_offset, const int32_t *stream_len,
-                                    int32_t amp_end_threshold, uint8_t *out_bytes, int32_t out_stride,
-                                    int32_t *out_nbytes, int32_t *out_nbits, int32_t *out_clock_idx,
-                                    int32_t *out_term_frame, int32_t *out_status, int32_t *out_corrected,
-                                    int32_t *out_margins, int32_t margin_stride, void *scratch,
-                                    int64_t scratch_bytes, void *hip_stream);
 
 /*
  * Same operation on HOST buffers: allocates device scratch, copies in, runs the

@@ -1013,82 +1013,6 @@ def test_tail_hint_partial_rounds_with_the_signal_end_anywhere_in_a_round(torch_
         assert (want["nbytes"] > 0).sum() > n // 2
 
 
-def test_grouped_staged_launch_equals_the_plain_one(torch_cuda):
-    """r5, ABI 3: afsk_demod_batch_grouped_staged writes its results in walk order into the caller's scratch and
-    permutes them to the stream numbers with a second kernel.  Seven rates cycling over 9000 streams with every kind of
-    row among them -- payloads of 0 ... full length, streams too short to decode (status 1), an invalid bit_frames
-    (status 3), rows that truncate (out_nbytes > out_stride) -- must give, bit for bit, what the plain grouped launch
-    gives, AND leave every byte of a row beyond min(out_nbytes, out_stride) as the caller had it.  The fallbacks
-    (scratch too small / NULL, a stride that is not a multiple of 4, fewer than four rates) are the plain launch."""
-    import ctypes as C
-    torch = torch_cuda
-    dev = "cuda:0"
-    n, total = 9000, 48000
-    rates = (12000, 6000, 2400, 1200, 600, 300, 160)
-    baud_a = np.asarray([rates[i % len(rates)] for i in range(n)], np.int32)
-    bf = (48000 // baud_a).astype(np.int32)
-    room = np.asarray([synth.one_second_payload(int(b)) for b in baud_a], np.int32)
-    plen = np.maximum(room - (np.arange(n) // len(rates)) % np.maximum(room + 1, 1), 0).astype(np.int32)
-    payload = synth.payload_bytes(31, 0, n, int(room.max()))
-    ts = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_a], np.int32)
-    off = np.arange(n, dtype=np.int64) * total
-    ln = np.full(n, total, np.int32)
-    ln[5::97] = 3000                                  # shorter than the sync window: status 1
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    x = torch.zeros(n * total, dtype=torch.int16, device=dev)
-    batch.modulate_batch(t(payload), t(plen), t(bf), t(ts), t(off), t(np.full(n, total, np.int32)), total, x, False)
-    bf_bad = bf.copy()
-    bf_bad[11::131] = 42                              # not a multiple of 4: status 3, refused by the kernel itself
-    lib = _native.lib()
-    for stride in (64, 344):                          # 64: the 12000 / 6000-baud rows truncate
-        plan = batch.GroupPlan(bf_bad, dev)
-        need = plan.scratch_bytes(stride)
-        assert need >= n * (stride + 24)
-
-        def run(staged, scratch_bytes=None, out_stride=stride):
-            o = batch.alloc_result(n, out_stride, dev)
-            o.flat.fill_(0xA5)                        # the caller's bytes
-            cor = torch.full((n,), -7, dtype=torch.int32, device=dev)
-            args = [plan.handle, x.data_ptr(), t(off).data_ptr(), t(ln).data_ptr(), 14000, o.bytes.data_ptr(), out_stride,
-                    o.nbytes.data_ptr(), o.nbits.data_ptr(), o.clock_idx.data_ptr(), o.term_frame.data_ptr(),
-                    o.status.data_ptr(), cor.data_ptr(), None, 0]
-            if staged:
-                sb = need if scratch_bytes is None else scratch_bytes
-                scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=dev)
-                _native.check(lib.afsk_demod_batch_grouped_staged(*args, scratch.data_ptr() if sb else None, sb, None))
-            else:
-                _native.check(lib.afsk_demod_batch_grouped(*args, None))
-            torch.cuda.synchronize()
-            return o.flat.cpu().numpy().copy(), cor.cpu().numpy().copy(), o.cpu()
-
-        plain_flat, plain_cor, plain = run(False)
-        staged_flat, staged_cor, staged = run(True)
-        assert np.array_equal(staged_flat, plain_flat), f"stride {stride}: staged and plain results differ"
-        assert np.array_equal(staged_cor, plain_cor)
-        # (the plain launch itself is checked against the oracle by every other test of this file; here: the rows)
-        nb = np.minimum(np.maximum(plain.nbytes, 0), stride)
-        col = np.arange(stride)[None, :]
-        assert (plain.bytes[col >= nb[:, None]] == 0xA5).all(), "bytes beyond nbytes were touched"
-        assert (plain.status[11::131] == 3).all() and (plain.status[5::97][plain.status[5::97] != 3] == 1).all()
-        assert (plain.nbytes > stride).any() == (stride == 64)
-        for sb in (0, need - 16):                     # no scratch / too little: the plain launch
-            f2, c2, _ = run(True, sb)
-            assert np.array_equal(f2, plain_flat) and np.array_equal(c2, plain_cor)
-        plan.close()
-    # a stride that is not a multiple of 4, and a three-rate plan: no staging, same results as ever
-    plan = batch.GroupPlan(bf_bad, dev)
-    assert plan.scratch_bytes(90) == 0
-    plan.close()
-    plan3 = batch.GroupPlan(np.asarray([(40, 80, 160)[i % 3] for i in range(n)], np.int32), dev)
-    assert plan3.scratch_bytes(64) == 0
-    plan3.close()
-    # and through batch.demod_batch (the path every grouped test of this file takes) against the oracle
-    got = REAL_DEMOD_BATCH(x, t(off), t(ln), bf, 14000, out_stride=344, validate=False, entry="grouped")
-    torch.cuda.synchronize()
-    want = O.demod_batch(x.cpu().numpy(), off, ln, bf, 14000, out_stride=344, n_threads=os.cpu_count() or 8)
-    assert_same(got.cpu(), want, "staged grouped launch vs oracle")
-
-
 def test_long_outputs_with_the_tail_hint_armed(torch_cuda, entry):
     """Launches large enough to arm the tail hint (partial rounds that run twice: the receiver state goes back and the
     deferred Hamming flushes of the round are repeated) of streams that decode to 1.0 - 1.5 KiB each -- sixteen to

@@ -200,7 +200,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.afsk_version() == 3
+    assert lib.afsk_version() == 2
     assert int(re.search(r"#define AFSK_ABI_VERSION (\d+)", hdr).group(1)) == lib.afsk_version()
 
 

@@ -13,7 +13,6 @@ namespace afsk {
 hipError_t launch_gate(const GateArgs&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_demod(const DemodArgs&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_demod_uniform(const DemodArgs&, hipStream_t) { return hipErrorUnknown; }
-hipError_t launch_permute_results(const PermuteArgs&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_modulate(ModulateArgs, int32_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_noise(NoiseArgs, int32_t, hipStream_t) { return hipErrorUnknown; }
 }
