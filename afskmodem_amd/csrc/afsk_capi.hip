@@ -630,8 +630,37 @@ struct GroupPlan {
             first += count[(size_t)bf];
         }
         h_upload.resize(2 * (size_t)n);
-        for (int32_t s = 0; s < n; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+        const int32_t window = sort_window();
+        if (window <= 0 || window >= n) {
+            for (int32_t s = 0; s < n; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+        } else {
+            // bucket order INSIDE windows of `window` consecutive streams (see sort_window)
+            std::vector<int32_t> wc(count.size());
+            size_t at = 0;
+            for (int32_t w0 = 0; w0 < n; w0 += window) {
+                const int32_t w1 = std::min(n, w0 + window);
+                std::fill(wc.begin(), wc.end(), 0);
+                for (int32_t s = w0; s < w1; s++) wc[(size_t)slot(h_bf[s])]++;
+                size_t run = at;
+                for (int32_t bf : order) { cursor[(size_t)bf] = (int32_t)run; run += (size_t)wc[(size_t)bf]; }
+                for (int32_t s = w0; s < w1; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+                at = run;
+            }
+        }
         if (n > 0) std::memcpy(h_upload.data() + n, h_bf, (size_t)n * 4);
+    }
+
+    // The walk visits the buckets one after the other INSIDE windows of this many consecutive streams (r5; 0 = over
+    // the whole batch, r4's form).  The 2048 streams in flight of a walk over the whole batch are spread over as many
+    // times the address range as there are rates cycling over the streams, and that alone costs 3.5 - 5 % (one rate
+    // read in that order: profiles/r5_exp37_address_order.txt).  Windows of 4096 streams -- two generations of
+    // resident wavefronts -- keep the streams in flight within 0.4 GB and the neighbouring wavefronts on one rate's
+    // code: -2.8 % for four cycling rates, -2.2 % for eighteen, unchanged at 4096 streams (1024: -3.7 / -3.1 % but
+    // +2 % at 4096 streams; profiles/r5_exp38_windowed_walk.txt).  AFSK_GROUP_WINDOW overrides (A/B runs).
+    static int32_t sort_window() {
+        const char* e = std::getenv("AFSK_GROUP_WINDOW");
+        if (e && *e) return (int32_t)std::atol(e);
+        return 4096;
     }
 
     // device part: index list + bit_frames either in storage the caller provides (2 n int32, copied

@@ -149,7 +149,8 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
  * different baud rates, each with its own streams: one baud rate per Receiver, :275-284; streams are
  * independent, :354-381).  The plan buckets the streams by bit_frames once (a stable sort on the host, one
  * upload of an index list + the bit_frames, 8 bytes per stream); afsk_demod_batch_grouped then decodes the
- * batch with ONE kernel launch that walks the streams bucket by bucket, so that the wavefronts resident on a
+ * batch with ONE kernel launch that walks the streams bucket by bucket (inside windows of 4096 consecutive streams,
+ * so that the streams in flight stay close in memory), so that the wavefronts resident on a
  * compute unit run the same rate's code: 3 - 12 % faster than stream order when four or more rates are mixed
  * (below that the plan keeps stream order; one rate: the kernel of afsk_demod_batch_uniform).  Nothing but a
  * kernel launch: asynchronous on hip_stream like every device entry, safe inside a stream capture, and

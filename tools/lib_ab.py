@@ -34,6 +34,9 @@ def main() -> None:
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--order", default="rotate", choices=["fixed", "rotate"])
     ap.add_argument("--rate-order", default="cycle", choices=["cycle", "blocks"], help="how --bauds are laid over the streams (bench.py --rate-order)")
+    ap.add_argument("--offset-transpose", type=int, default=0,
+                    help="K > 1: stream s reads the samples of stream (s %% K) * (n / K) + s / K -- a stream-order walk then jumps "
+                         "through the input like a rate-sorted walk over K cycling rates (the round-trip figure is meaningless then)")
     ap.add_argument("--stride-align", type=int, default=0, help="round the output row stride up to a multiple of this (0: bench.py's)")
     a = ap.parse_args()
     import numpy as np
@@ -50,9 +53,16 @@ def main() -> None:
     n, stride = sh.n_local, sh.stride
     if a.stride_align > 0:
         stride = -(-stride // a.stride_align) * a.stride_align
+    if a.offset_transpose > 1:
+        k = a.offset_transpose
+        idx = torch.arange(n, device=ctx.dev)
+        src = (idx % k) * (n // k) + idx // k
+        sh.off = sh.off[src.clamp_(max=n - 1)].contiguous()
     sptr = C.c_void_p(ctx.cur.cuda_stream)
     libs, calls, outs = [], [], []
     for path in a.libs:
+        path, _, win = path.partition("@")           # "lib.so@2048": AFSK_GROUP_WINDOW for this entry's group plan
+        os.environ["AFSK_GROUP_WINDOW"] = win or "0"
         L = C.CDLL(os.path.abspath(path))
         for name, (res, at) in _native.SIGNATURES.items():
             fn = getattr(L, name)
@@ -75,7 +85,7 @@ def main() -> None:
             mk = lambda x, o=o: (x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.bf.data_ptr(), 14000, n,   # noqa: E731
                                  o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(), o.clock_idx.data_ptr(),
                                  o.term_frame.data_ptr(), o.status.data_ptr(), sptr)
-        libs.append(os.path.basename(path))
+        libs.append(os.path.basename(path) + (("@" + win) if win else ""))
         calls.append((fn, [mk(x) for x in sh.inputs]))
         outs.append(o)
     nin = len(sh.inputs)
