@@ -609,7 +609,11 @@ struct GroupPlan {
     }
 
     static bool valid_bf(int32_t bf) { return bf >= 4 && (bf & 3) == 0 && 2 * bf < AFSK_SYNC_WINDOW; }
-    bool sorted() const { return groups.size() >= kSortFromGroups; }
+    bool sorted() const { return groups.size() >= sort_from(); }
+    static size_t sort_from() {                  // AFSK_GROUP_SORT_FROM overrides (A/B runs)
+        const char* e = std::getenv("AFSK_GROUP_SORT_FROM");
+        return (e && *e) ? (size_t)std::atol(e) : kSortFromGroups;
+    }
 
     // host part: buckets and permutation (stable inside a bucket: ascending stream number)
     void bucket(const int32_t* h_bf, int32_t n_streams) {

@@ -61,8 +61,13 @@ def main() -> None:
     sptr = C.c_void_p(ctx.cur.cuda_stream)
     libs, calls, outs = [], [], []
     for path in a.libs:
-        path, _, win = path.partition("@")           # "lib.so@2048": AFSK_GROUP_WINDOW for this entry's group plan
+        path, _, win = path.partition("@")           # "lib.so@2048": AFSK_GROUP_WINDOW for this entry's group plan;
+        win, _, sort_from = win.partition(":")       # "lib.so@4096:3": ... and AFSK_GROUP_SORT_FROM
         os.environ["AFSK_GROUP_WINDOW"] = win or "0"
+        if sort_from:
+            os.environ["AFSK_GROUP_SORT_FROM"] = sort_from
+        else:
+            os.environ.pop("AFSK_GROUP_SORT_FROM", None)
         L = C.CDLL(os.path.abspath(path))
         for name, (res, at) in _native.SIGNATURES.items():
             fn = getattr(L, name)
@@ -85,7 +90,7 @@ def main() -> None:
             mk = lambda x, o=o: (x.data_ptr(), sh.off.data_ptr(), sh.ln.data_ptr(), sh.bf.data_ptr(), 14000, n,   # noqa: E731
                                  o.bytes.data_ptr(), stride, o.nbytes.data_ptr(), o.nbits.data_ptr(), o.clock_idx.data_ptr(),
                                  o.term_frame.data_ptr(), o.status.data_ptr(), sptr)
-        libs.append(os.path.basename(path) + (("@" + win) if win else ""))
+        libs.append(os.path.basename(path) + (("@" + win) if win else "") + ((":" + sort_from) if sort_from else ""))
         calls.append((fn, [mk(x) for x in sh.inputs]))
         outs.append(o)
     nin = len(sh.inputs)
