@@ -74,7 +74,17 @@ WORKLOADS = {
     # not a BASELINE config: --workload custom --bauds 480,12000 [--streams N] times any baud mix
     # (profiles of the rates furthest from the roofline)
     "custom": (4096, (1200,), None, "custom: streams x 1 s, clean, bauds from --bauds, per GPU"),
+    # r6: the config5 shard as a gate-cut capture would deliver it -- every stream starts with its own pseudo-random
+    # lead-in of 0 ... 2047 samples of low-level noise (|x| < 600) before the Transmitter frame, so the clock index
+    # (ref:322-339) is arbitrary: 7 of 8 streams have (2 * ci) & 15 != 0 and none takes the ci == 0 shortcut
+    "config5_lead": (65536, (1200,), None, "config5 shard with a per-stream lead-in of 0..2047 noise samples (arbitrary clock index): 65536 streams x 1 s @1200 baud, per GPU"),
 }
+# workloads whose streams start with a lead-in: exclusive upper bound of the per-stream lead (samples); --lead N|random
+# sets it for `custom` (N: the same lead for every stream)
+LEADS = {"config5_lead": 2048}
+LEAD_FIXED = {}                 # name -> fixed lead (samples) instead of a per-stream random one
+LEAD_NOISE = 600                # |x| < this in the lead-in (the limiter's dead zone is 512, the squelch 14000)
+LEAD_SEED = 777
 HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
 NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress")   # SURVEY 8(f) rows (+ the egress) as sub-records at N = 1
 RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
@@ -117,7 +127,7 @@ def plan(world: int, workload: str = "", sub=None, streams: int = 0) -> dict:
     elif workload or streams:
         names = []
     else:
-        names = ["config2", "config3", "config4"] + list(DEFAULT_RIDERS) if world == 1 else ["config2"]
+        names = ["config2", "config3", "config4", "config5_lead"] + list(DEFAULT_RIDERS) if world == 1 else ["config2"]
     riders = NEXT_ROWS + tuple(RATES_ROWS)
     for x in [main] + names:
         if x not in WORKLOADS and x not in riders:
@@ -275,6 +285,14 @@ class Shard:
         assert adist.shard_range(self.n_total, ctx.rank, ctx.world) == (self.first, self.first + n_local)
         self.bf_h, self.plen_h, self.payload_h, ts_h = self.host_meta(self.first, n_local, bauds)
         self.off, self.ln = batch.uniform_layout(n_local, STREAM_LEN, ctx.dev)
+        # lead-in workloads: the frame of stream s starts lead[s] samples into its slot (and loses as many samples of
+        # its 4800-sample silent tail); the demodulator still gets the whole slot
+        self.lead_h = self.host_leads(name, self.first, n_local)
+        if self.lead_h is not None:
+            lead_d = ctx.t(self.lead_h.astype(np.int64))
+            self._moff, self._mln = self.off + lead_d, (self.ln.to(torch.int64) - lead_d).to(torch.int32)
+        else:
+            self._moff, self._mln = self.off, self.ln
         self.bf = ctx.t(self.bf_h)
         self._payload_d, self._plen_d, self._ts_d = ctx.t(self.payload_h), ctx.t(self.plen_h), ctx.t(ts_h)
         x = torch.empty(n_local * STREAM_LEN, dtype=torch.int16, device=ctx.dev)
@@ -314,15 +332,47 @@ class Shard:
         ts_h = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_arr], np.int32)
         return bf_h, plen_h, payload_h, ts_h
 
+    @staticmethod
+    def host_leads(name: str, first: int, n: int):
+        """Per-stream lead-in (samples) of a lead-in workload, a pure function of the GLOBAL stream index; None otherwise."""
+        if name in LEAD_FIXED:
+            return np.full(n, LEAD_FIXED[name], np.int32)
+        if name not in LEADS:
+            return None
+        from afskmodem_amd import synth
+        g = np.arange(first, first + n, dtype=np.uint64)
+        return (synth._hash32((g * np.uint64(2654435761) + np.uint64(LEAD_SEED)) & np.uint64(0xFFFFFFFF)) % np.uint64(LEADS[name])).astype(np.int32)
+
+    def write_leads(self) -> None:
+        """Low-level integer noise (|x| < LEAD_NOISE, a hash of global stream index and position) over the lead-in."""
+        torch = self.ctx.torch
+        x2 = self.inputs[0].view(self.n_local, STREAM_LEN)
+        width = int(self.lead_h.max()) if self.lead_h.size else 0
+        if width <= 0:
+            return
+        lead_d = self.ctx.t(self.lead_h.astype(np.int64))
+        for s0 in range(0, self.n_local, 8192):          # (bounded temporaries: 8192 x 2048 int64)
+            s1 = min(self.n_local, s0 + 8192)
+            g = torch.arange(self.first + s0, self.first + s1, device=self.ctx.dev, dtype=torch.int64)[:, None]
+            j = torch.arange(width, device=self.ctx.dev, dtype=torch.int64)[None, :]
+            h = (g * 2048 + j) * 0x9E3779B1 + LEAD_SEED
+            h = (h ^ (h >> 15)) * 0x85EBCA6B & 0xFFFFFFFF
+            h = (h ^ (h >> 13)) & 0xFFFFFFFF
+            noise = (h % (2 * LEAD_NOISE - 1) - (LEAD_NOISE - 1)).to(torch.int16)
+            head = x2[s0:s1, :width]
+            head.copy_(torch.where(j < lead_d[s0:s1, None], noise, head))
+
     def regenerate(self, snr_db, seed: int = 99) -> None:
-        """(Re)write inputs[0]: Transmitter frames (+ additive noise at snr_db)."""
+        """(Re)write inputs[0]: Transmitter frames (+ the lead-in, + additive noise at snr_db)."""
         from afskmodem_amd import batch, synth
         x = self.inputs[0]
         # the .wav writer's decimate/duplicate quirk (ref:239-244) is part of every Transmitter.save
         # stream; at 12000 baud it destroys the mark tone (in the reference too), so a custom
         # workload with that rate uses the ideal frames
-        batch.modulate_batch(self._payload_d, self._plen_d, self.bf, self._ts_d, self.off, self.ln,
+        batch.modulate_batch(self._payload_d, self._plen_d, self.bf, self._ts_d, self._moff, self._mln,
                              STREAM_LEN, x, 12000 not in self.bauds)
+        if self.lead_h is not None:
+            self.write_leads()
         if snr_db is not None:
             batch.add_noise_batch(x, self.off, self.ln, STREAM_LEN, synth.snr_to_scale_q24(snr_db),
                                   seed=seed, stream_idx_base=self.first)
@@ -567,6 +617,10 @@ def measure(ctx: Ctx, sh: Shard, steps: int, warmup: int, preroll_ms: float, gat
                      "frac_at_median": None if ev_med is None else round(alg_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "full_buffer_gbs": round((2 * n_local * STREAM_LEN) / (kernel_ms * 1e-3) / 1e9, 1)},
         "input_buffers_rotated": nin,
+        # streams whose clock index (ref:322-339) is not a multiple of 8 samples / is not zero: what a capture that does
+        # not start on the training sequence's first sample looks like (r6; 0.0 / 0.0 for every Transmitter-shaped batch)
+        "clock_index_unaligned_share": round(float(((res.clock_idx.astype(np.int64) * 2) & 15).astype(bool).mean()), 4),
+        "clock_index_nonzero_share": round(float((res.clock_idx != 0).mean()), 4),
         "roundtrip_match_rate": roundtrip_rate,
         "checked_step": chk_step,
         "all_timed_steps_identical": all_steps_equal,
@@ -821,6 +875,8 @@ def _sub_summary(name: str, rec: dict) -> dict:
         out["frac_overwrite"] = rec["roofline"]["frac_overwrite_in_place"]
     if "entry" in rec:
         out["entry"] = rec["entry"].replace("afsk_demod_batch", "demod")
+    if rec.get("clock_index_unaligned_share"):
+        out["ci_unaligned"] = rec["clock_index_unaligned_share"]
     if "ber_curve" in rec:
         rows = rec["ber_curve"]
         out["ber"] = {str(r["snr_db"]): r["ber_gpu_all_streams"] for r in rows}
@@ -1168,6 +1224,8 @@ def main() -> None:
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--bauds", default="", help="with --workload custom: comma list of baud rates cycled over the streams")
+    ap.add_argument("--lead", default="", help="with --workload custom: lead-in before every frame -- N (samples, the same for every "
+                    "stream) or 'random' (per stream 0 ... 2047, like config5_lead): low-level noise, arbitrary clock index")
     ap.add_argument("--rate-order", default="cycle", choices=["cycle", "blocks"],
                     help="custom workloads: baud of stream i = bauds[i %% k] (cycle) or contiguous blocks of n / k streams (blocks)")
     ap.add_argument("--preroll-ms", type=float, default=300.0,
@@ -1203,6 +1261,15 @@ def main() -> None:
     if args.bauds:
         bl = tuple(int(b) for b in args.bauds.split(","))
         WORKLOADS["custom"] = (WORKLOADS["custom"][0], bl, None, f"custom: streams x 1 s, clean, bauds {list(bl)}, per GPU")
+    if args.lead:
+        if args.lead == "random":
+            LEADS["custom"] = 2048
+        else:
+            LEAD_FIXED["custom"] = int(args.lead)
+            if not 0 <= LEAD_FIXED["custom"] <= 4000:
+                raise SystemExit("--lead: 0 ... 4000 samples (the frame must start inside the 4096-sample sync window)")
+        d = WORKLOADS["custom"]
+        WORKLOADS["custom"] = (d[0], d[1], d[2], d[3] + f", lead-in {args.lead}")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher.  This process never touches the GPU and never
         # imports torch: the devices are counted in sysfs (KFD topology).

@@ -244,7 +244,14 @@ def test_headline_workload_is_the_same_at_every_n():
     assert blocks[1]["workload"] == blocks[2]["workload"] == blocks[8]["workload"]
     assert blocks[8]["streams_total"] == 524288
     one, two = bench.plan(1), bench.plan(2)
-    assert one["subs"] == ["config2", "config3", "config4"]
+    assert one["subs"] == ["config2", "config3", "config4", "config5_lead"]
+    # r6: the lead-in workload -- leads are a pure function of the GLOBAL stream index (a rank's shard of a larger job
+    # gets the leads of its own streams), 0 ... 2047, and 7 of 8 clock indices are not multiples of 8 samples
+    la = bench.Shard.host_leads("config5_lead", 0, 65536)
+    lb = bench.Shard.host_leads("config5_lead", 32768, 4096)
+    assert la.min() == 0 and la.max() == 2047 and (la[32768:32768 + 4096] == lb).all()
+    assert 0.85 < float(((2 * la) & 15).astype(bool).mean()) < 0.90
+    assert bench.Shard.host_leads("config5", 0, 16) is None
     assert one["next"] == ["f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"] == list(bench.DEFAULT_RIDERS)
     # the egress mirror and the 4096-stream table are measured on request only
     assert bench.plan(1, "", "f5_wav_egress,rates_4096")["next"] == ["f5_wav_egress", "rates_4096"]
