@@ -110,19 +110,19 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     const int32_t NR = (K + SPR - 1) / SPR;
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
-    const int byte0 = 2 * ci;                                  // ring byte of symbol 0
-    // Tail hint (see kProbes): for large launches, and only on the aligned round loops (a second copy of
-    // each, so that streams without the hint run exactly the code they ran before).  The UNIFORM kernels of
+    // r6: the stream is re-based on the clock index (FastRing::rebase): symbol 0 sits at a 16-byte-aligned ring byte
+    // whatever ci is, so every stream runs the aligned round loops (until r5: a re-aligning copy of each, and no tail
+    // hint, for the 7 of 8 arbitrary clock indices with (2 * ci) & 15 != 0)
+    const int byte0 = fr.template rebase<(FLAGS & 4) ? 0 : 2>(xs, len, 2 * ci);   // ring byte of symbol 0
+    // Tail hint (see kProbes): for large launches (a second copy of each round loop, so that streams without the hint
+    // run exactly the code they ran before).  The UNIFORM kernels of
     // bit_frames 4 / 8 take it from kHintMinStreamsShort4 / 8 streams on (at 4096 streams it costs them 3 %).
     // (Until r5 those two went without it inside the per-stream kernel -- five- and ten-slice rounds, short of scalar
     // registers: with the r5 build the spills are gone and the hint is worth 8 % there: profiles/r5_exp18_*.)
-    constexpr bool HINT = true;
-    constexpr int kAlignMask = GP ? 0 : (WM ? WmGeom<WM ? BF : 60>::RW - 1 : (MULTI ? MultiGeom<MULTI ? BF : 4>::RW - 1 : (BF == 20 ? 7 : 15)));   // GP reads 2-byte-aligned dwords
-    const bool aligned = (byte0 & kAlignMask) == 0;               // 2400 baud reads 8-byte pieces
-    const bool hinted = HINT && hint && aligned;
+    const bool hinted = hint;
     if (hinted) {
         constexpr int kRoundBytes = MULTI ? 1024 * MultiGeom<MULTI ? BF : 4>::R : (WM ? WmGeom<WM ? BF : 60>::RBYTES : (GP ? GpGeom<GP ? BF : 128>::RBYTES : 5120));
-        fr.request_probes((uint32_t)len * 2u, byte0, kRoundBytes);
+        fr.request_probes((uint32_t)len * 2u - (uint32_t)(2 * ci - byte0), byte0, kRoundBytes);
     }
     // chunks entirely below the clock index are free already
     {
@@ -136,14 +136,11 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     rxd_init(rd);
 #define AFSK_ROUNDS(FN)                                                                                              \
     do {                                                                                                             \
-        if (!aligned) FN<BF, FLAGS, false, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
-        else if (HINT && BIG && hinted) FN<BF, FLAGS, true, HINT && BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
-        else FN<BF, FLAGS, true, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
+        if (BIG && hinted) FN<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
+        else FN<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
     } while (0)
-    if constexpr (GP) {
-        if (HINT && BIG && hinted) gp_rounds<BF, FLAGS, HINT && BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-        else gp_rounds<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);
-    } else if constexpr (WM) AFSK_ROUNDS(wm_rounds);
+    if constexpr (GP) AFSK_ROUNDS(gp_rounds);
+    else if constexpr (WM) AFSK_ROUNDS(wm_rounds);
     else if constexpr (MULTI) AFSK_ROUNDS(multi_rounds);
     else AFSK_ROUNDS(fast_rounds);
 #undef AFSK_ROUNDS

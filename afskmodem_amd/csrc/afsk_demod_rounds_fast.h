@@ -102,17 +102,16 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
     }
 }
 
-// The round loop.  ALIGNED = the wave-uniform shift (2*ci) & 15 is zero (always true for
-// Transmitter-generated streams, whose clock index is a multiple of the training period):
-// five aligned ds_read_b128 feed the arithmetic directly.  Otherwise six reads + v_alignbyte.
-template <int BF, int FLAGS, bool ALIGNED, bool HINTED>
+// The round loop.  byte0 -- the ring byte of symbol 0 -- is a multiple of 16 (FastRing::rebase, r6): five aligned
+// ds_read_b128 feed the arithmetic directly.  (Until r5 streams whose clock index was not a multiple of 8 samples ran a
+// second form: six reads + v_alignbyte per dword, every round.)
+template <int BF, int FLAGS, bool HINTED>
 __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                             uint32_t amp_thr, RxDeferred& rd,
                                             unsigned long long* words, uint8_t* out_row,
                                             int out_stride, int32_t* margins, int32_t mstride) {
     constexpr int SPR = 2560 / BF;                                // symbols per 5 KiB round
     const int lane = fr.lane;
-    const int shift = byte0 & 15;
     for (int r = 0; r < NR; r++) {
         // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
         // (B_r .. B_r+5) from the oldest resident one; chunks through B_r+15 are issued, so the
@@ -120,79 +119,42 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         int32_t Kr = K;                    // symbols this round may use (fewer: a partial round, see holding_wait)
         bool partial = false;
         RxDeferred saved;
-        const int last = byte0 + 5120 * r + 5119 + (ALIGNED ? 0 : 16);                 // last byte read
+        const int last = byte0 + 5120 * r + 5119;                                      // last byte read
         if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed 5-chunks-per-round schedule
             Kr = fr.template holding_wait<(FLAGS & 4) ? 0 : 2>(last, K, r * SPR, byte0, 2 * BF, partial);
             if (partial) saved = rd;
         } else {
             fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
-            if constexpr (HINTED) fr.template eval_probes<fine_probes(5120)>(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : 16, 2 * BF);
+            if constexpr (HINTED) fr.template eval_probes<fine_probes(5120)>(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, 0, 2 * BF);
         }
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
         if constexpr (BF == 20) {
             // 2400 baud: lane l takes symbol l (bytes 40l .. 40l+39 of the round) and symbol 64 + l
             // (2560 bytes further): ten 8-byte reads; the 40-byte lane stride spreads 32 lanes over
-            // all 64 banks.  ALIGNED here means (2*ci) & 7 == 0.
+            // all 64 banks.
 #pragma unroll
             for (int piece = 0; piece < 2; piece++) {
                 const int pb = rb + 2560 * piece + 40 * lane;
-                if constexpr (ALIGNED) {
 #pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((pb + 8 * j) & (kRingBytes - 1)));
-                        x[10 * piece + 2 * j] = t2[0]; x[10 * piece + 2 * j + 1] = t2[1];
-                    }
-                } else {
-                    const int ab = pb & ~7;
-                    uint32_t W[12];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((ab + 8 * j) & (kRingBytes - 1)));
-                        W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
-                    }
-                    uint32_t y[10];
-                    switch (byte0 & 7) {
-                        case 2: realign_n<2, 12, 10>(W, y); break;
-                        case 4: realign_n<4, 12, 10>(W, y); break;
-                        default: realign_n<6, 12, 10>(W, y); break;
-                    }
-#pragma unroll
-                    for (int d = 0; d < 10; d++) x[10 * piece + d] = y[d];
+                for (int j = 0; j < 5; j++) {
+                    const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((pb + 8 * j) & (kRingBytes - 1)));
+                    x[10 * piece + 2 * j] = t2[0]; x[10 * piece + 2 * j + 1] = t2[1];
                 }
             }
-        } else if constexpr (ALIGNED) {
-            if (rb + 5120 <= kRingBytes) {                              // no wrap in this round
-                const uint8_t* src = fr.ring + rb + 80 * lane;
+        } else if (rb + 5120 <= kRingBytes) {                           // no wrap in this round
+            const uint8_t* src = fr.ring + rb + 80 * lane;
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
-                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
-                }
-            } else {
-                const int pb = rb + 80 * lane;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((pb + 16 * j) & (kRingBytes - 1)));
-                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
-                }
+            for (int j = 0; j < 5; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
+                x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
             }
         } else {
-            const int ab = (rb + 80 * lane) & ~15;
-            uint32_t W[24];
+            const int pb = rb + 80 * lane;
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((ab + 16 * j) & (kRingBytes - 1)));
-                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
-            }
-            switch (shift) {
-                case 2: realign<2>(W, x); break;
-                case 4: realign<4>(W, x); break;
-                case 6: realign<6>(W, x); break;
-                case 8: realign<8>(W, x); break;
-                case 10: realign<10>(W, x); break;
-                case 12: realign<12>(W, x); break;
-                default: realign<14>(W, x); break;
+            for (int j = 0; j < 5; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((pb + 16 * j) & (kRingBytes - 1)));
+                x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
             }
         }
         // the reads above have returned (their values are in x): refill the 5 chunks this

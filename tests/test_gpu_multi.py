@@ -412,9 +412,11 @@ def test_bench_default_line_at_n1_is_compact_and_complete():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["match_rate"] == 1.0 and d["roundtrip_match_rate"] == 1.0
     subs = d["sub_records"]
-    assert {"config2", "config3", "config4", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"} == set(subs)
-    for name in ("config2", "config3", "config4", "f1_modulate", "f3_wav_ingest"):
+    assert {"config2", "config3", "config4", "config5_lead", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"} == set(subs)
+    for name in ("config2", "config3", "config4", "config5_lead", "f1_modulate", "f3_wav_ingest"):
         assert subs[name]["match_rate"] == 1.0, name
+    # r6: the lead-in workload (arbitrary clock index: 7 of 8 streams off the 16-byte grid) decodes and is reported
+    assert subs["config5_lead"]["roundtrip"] == 1.0 and 0.85 < subs["config5_lead"]["ci_unaligned"] < 0.90
     assert "error" not in json.dumps(subs) and "incomplete" not in d
     assert subs["config4"]["ber_equals_cpu"] is True
     full = json.load(open(os.path.join(root, d["full_record"])))
