@@ -57,6 +57,7 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
     "afsk_group_plan_create": (C.c_int, [_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "afsk_group_plan_create_ragged": (C.c_int, [_i32p, _i32p, C.c_int32, C.POINTER(C.c_void_p)]),
     "afsk_group_plan_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, C.c_int32]),
     "afsk_group_plan_destroy": (C.c_int, [C.c_void_p]),
     "afsk_demod_batch_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -270,7 +270,16 @@ _PLAN_CACHE_MAX = 8
 _PLAN_CACHE_LOCK = threading.Lock()
 
 
-def _cached_plan(bit_frames, n: int, dev) -> "GroupPlan":
+def lengths_ragged(stream_len_host) -> bool:
+    """The rule of ``GroupPlan::lengths_ragged`` (afsk_capi.hip): do the stream lengths differ enough for a
+    longest-first walk to pay -- the shortest stream below 3/4 of the longest, eight streams or more."""
+    if stream_len_host is None:
+        return False
+    a = np.asarray(stream_len_host)
+    return bool(a.size >= 8 and int(a.max()) > 0 and int(a.min()) * 4 < int(a.max()) * 3)
+
+
+def _cached_plan(bit_frames, n: int, dev, stream_len_host=None) -> "GroupPlan":
     """Plans built on behalf of ``demod_batch`` calls that did not bring one: kept per (device, contents)
     so that decoding the same batch layout again costs one hash of the array.  Thread-safe: look-up, insert and
     eviction happen under one lock, and an evicted plan is only DROPPED from the cache -- it is freed (after a
@@ -281,13 +290,19 @@ def _cached_plan(bit_frames, n: int, dev) -> "GroupPlan":
     if arr.size not in (1, n):
         raise ValueError(f"bit_frames holds {arr.size} values for {n} streams (1 or {n} expected)")
     arr = np.ascontiguousarray(np.broadcast_to(arr.reshape(-1) if arr.ndim else arr, (n,)))
-    key = (str(dev), n, hash(arr.tobytes()))
+    lens = None
+    if lengths_ragged(stream_len_host):                      # (equal lengths: the plan does not depend on them)
+        lens = np.ascontiguousarray(np.asarray(stream_len_host, dtype=np.int32).reshape(-1))
+        if lens.size != n:
+            raise ValueError(f"stream_len_host holds {lens.size} values for {n} streams")
+    key = (str(dev), n, hash(arr.tobytes()), None if lens is None else hash(lens.tobytes()))
     with _PLAN_CACHE_LOCK:
         plan = _PLAN_CACHE.pop(key, None)
-        if plan is not None and np.array_equal(plan.bit_frames, arr):
+        if plan is not None and np.array_equal(plan.bit_frames, arr) and (
+                lens is None if plan.stream_len is None else (lens is not None and np.array_equal(plan.stream_len, lens))):
             _PLAN_CACHE[key] = plan                          # most recently used last
             return plan
-    fresh = GroupPlan(arr, dev)                              # (built outside the lock: an 8 B / stream upload)
+    fresh = GroupPlan(arr, dev, stream_len=lens)             # (built outside the lock: an 8 B / stream upload)
     with _PLAN_CACHE_LOCK:
         _PLAN_CACHE[key] = fresh
         while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
@@ -300,18 +315,31 @@ class GroupPlan:
     (``afsk_group_plan_create``): the streams bucketed by rate, decoded by ONE launch that walks them bucket
     by bucket (neighbouring wavefronts run the same rate's code), outputs at the original stream numbers.
     Build it once per batch layout and pass it to ``demod_batch(..., plan=...)``; it belongs to the device
-    that was current when it was built."""
+    that was current when it was built.
 
-    def __init__(self, bit_frames, device=None):
+    ``stream_len`` (r6, ``afsk_group_plan_create_ragged``): the HOST-side lengths of the streams.  One wavefront decodes
+    one stream whatever its length, and a workgroup of four holds its share of a CU until its longest stream ends: when
+    the lengths differ (shortest below 3/4 of the longest) the walk takes the longest streams first inside every window
+    of 4096 streams and every rate -- also for a single rate.  Speed only: the outputs are the same."""
+
+    def __init__(self, bit_frames, device=None, stream_len=None):
         torch = _torch()
         _native.require_device()
+        _drain_parked_plans()
         self.bit_frames = np.ascontiguousarray(np.asarray(bit_frames, dtype=np.int32).reshape(-1))
         self.n = int(self.bit_frames.size)
+        self.stream_len = None
+        if stream_len is not None:
+            self.stream_len = np.ascontiguousarray(np.asarray(stream_len, dtype=np.int32).reshape(-1))
+            if self.stream_len.size != self.n:
+                raise ValueError(f"stream_len holds {self.stream_len.size} values for {self.n} streams")
         self.device = _default_device(device)
         self._h = C.c_void_p()
+        i32 = C.POINTER(C.c_int32)
         with torch.cuda.device(self.device):
-            _native.check(_native.lib().afsk_group_plan_create(
-                self.bit_frames.ctypes.data_as(C.POINTER(C.c_int32)), self.n, C.byref(self._h)))
+            _native.check(_native.lib().afsk_group_plan_create_ragged(
+                self.bit_frames.ctypes.data_as(i32),
+                None if self.stream_len is None else self.stream_len.ctypes.data_as(i32), self.n, C.byref(self._h)))
 
     @property
     def handle(self):
@@ -335,18 +363,62 @@ class GroupPlan:
             self._h = C.c_void_p()
 
     def __del__(self):
+        # Launches that use the plan's device index list may still be queued: free it behind a device synchronise.
+        # Not inside a HIP stream capture (the last DemodResult of a cached plan may be dropped there, e.g. by
+        # rebinding ``res = demod_batch(...)`` while capturing): a synchronise would invalidate the capture, so the
+        # handle is parked and freed by the next plan construction / explicit ``release_parked_plans()`` outside one.
+        h, self._h = self._h, C.c_void_p()
+        if not h:
+            return
         try:
-            if self._h:
-                _torch().cuda.synchronize(self.device)     # launches may still be queued
-                self.close()
-        except Exception:  # noqa: BLE001  (interpreter shutdown)
-            pass
+            torch = _torch()
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("capturing")
+            torch.cuda.synchronize(self.device)
+            _native.lib().afsk_group_plan_destroy(h)
+        except Exception:  # noqa: BLE001  (capturing, a failed synchronise, interpreter shutdown): never drop the handle
+            try:
+                with _PARKED_LOCK:
+                    _PARKED_PLANS.append((h, self.device))
+            except Exception:  # noqa: BLE001
+                pass
+
+
+_PARKED_PLANS: list = []          # (handle, device) of plans whose owner died where no synchronise was possible
+_PARKED_LOCK = threading.Lock()
+
+
+def _drain_parked_plans() -> None:
+    if not _PARKED_PLANS:
+        return
+    torch = _torch()
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:  # noqa: BLE001
+        return
+    with _PARKED_LOCK:
+        todo, _PARKED_PLANS[:] = list(_PARKED_PLANS), []
+    for h, dev in todo:
+        try:
+            torch.cuda.synchronize(dev)
+            _native.lib().afsk_group_plan_destroy(h)
+        except Exception:  # noqa: BLE001
+            with _PARKED_LOCK:
+                _PARKED_PLANS.append((h, dev))
+
+
+def release_parked_plans() -> int:
+    """Free the plans whose last reference went away inside a stream capture; returns how many are still parked."""
+    _drain_parked_plans()
+    return len(_PARKED_PLANS)
 
 
 def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshold: int = 14000,
                 out: DemodResult | None = None, out_stride: int | None = None, stream=None,
                 validate: bool = True, diagnostics: bool = False,
-                margin_stride: int | None = None, entry: str = "auto", plan: "GroupPlan | None" = None) -> DemodResult:
+                margin_stride: int | None = None, entry: str = "auto", plan: "GroupPlan | None" = None,
+                stream_len_host=None) -> DemodResult:
     """One kernel launch over n independent streams resident in HBM.
 
     samples        int16 CUDA tensor holding every stream
@@ -367,6 +439,10 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
                    (``validate=False``); the grouped and mixed entries write status 3 for such streams.
     plan           a ``GroupPlan`` built from this batch's host-side bit_frames: reused across calls
                    (otherwise "grouped" builds one per call: a sort and an n * 4 byte upload)
+    stream_len_host  the stream lengths as a HOST array, when the caller has them (r6): a RAGGED batch -- shortest
+                   stream below 3/4 of the longest -- with host-side bit_frames then goes through a plan whose walk
+                   takes the longest streams first (``GroupPlan(stream_len=)``), also when it has one rate; ignored
+                   for ``entry="uniform"`` / ``"mixed"``, with ``plan=`` and for device-side bit_frames
     Asynchronous on ``stream`` (default: torch's current stream).
     """
     torch = _torch()
@@ -397,12 +473,13 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
         if plan.n != n or plan.device != dev:
             raise ValueError(f"the plan covers {plan.n} streams on {plan.device}, the batch {n} on {dev}")
         entry = "grouped"
-    ubf = None if entry in ("mixed", "grouped") else _uniform_bit_frames(bit_frames, n)
+    ragged = plan is None and host_bf and entry in ("auto", "grouped") and lengths_ragged(stream_len_host)
+    ubf = None if (entry in ("mixed", "grouped") or ragged) else _uniform_bit_frames(bit_frames, n)
     if entry == "uniform" and ubf is None:
         raise ValueError("entry='uniform' needs ONE bit_frames value (an int or an all-equal host sequence)")
     if entry == "grouped" and plan is None and not host_bf:
         raise ValueError("entry='grouped' needs host-side bit_frames (or plan=): a device tensor is never inspected")
-    grouped = entry == "grouped" or (entry == "auto" and ubf is None and host_bf)
+    grouped = entry == "grouped" or ragged or (entry == "auto" and ubf is None and host_bf)
     fresh = False                      # tensors created (zero-filled / uploaded) inside this call
     if out is None:
         if out_stride is None:
@@ -437,7 +514,7 @@ def demod_batch(samples, stream_offset, stream_len, bit_frames, amp_end_threshol
             return out
         if grouped:
             if plan is None:
-                plan = _cached_plan(bit_frames, n, dev)
+                plan = _cached_plan(bit_frames, n, dev, stream_len_host if ragged else None)
             _native.check(lib.afsk_demod_batch_grouped(
                 plan.handle, samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(),
                 threshold_lt(amp_end_threshold), out.bytes.data_ptr(), stride, out.nbytes.data_ptr(),

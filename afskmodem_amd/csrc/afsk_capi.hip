@@ -603,21 +603,38 @@ struct GroupPlan {
     int32_t* d_index = nullptr;                  // [n] the permutation; followed, in the same storage, by
     int32_t* d_bf = nullptr;                     // [n] bit_frames by stream number (the kernel's per-stream switch reads it)
     bool own_index = false;
+    bool by_length = false;                      // r6: inside every window and bucket the longest streams come first
 
     ~GroupPlan() {
         if (own_index && d_index) (void)hipFree(d_index);
     }
 
     static bool valid_bf(int32_t bf) { return bf >= 4 && (bf & 3) == 0 && 2 * bf < AFSK_SYNC_WINDOW; }
-    bool sorted() const { return groups.size() >= sort_from(); }
+    bool sorted() const { return by_length || groups.size() >= sort_from(); }
     static size_t sort_from() {                  // AFSK_GROUP_SORT_FROM overrides (A/B runs)
         const char* e = std::getenv("AFSK_GROUP_SORT_FROM");
         return (e && *e) ? (size_t)std::atol(e) : kSortFromGroups;
     }
 
+    // Ragged batches (r6).  One wavefront decodes one stream whatever its length, and the four wavefronts of a
+    // workgroup share its LDS allocation: a workgroup holds its quarter of a CU until its LONGEST stream ends, so four
+    // neighbours of 0.25 / 0.25 / 0.25 / 4 s keep three wave slots idle for most of the group's life, and the launch ends
+    // when the last long stream does.  With the stream lengths visible to the host (h_len) the walk therefore takes,
+    // inside every window and rate bucket, the longest streams first (stable: equal lengths keep stream order) -- the
+    // four streams of a workgroup are then neighbours in length, and what a window dispatches last is short.  Only when
+    // the lengths differ enough to matter: the shortest stream below 3/4 of the longest (a batch of equal lengths keeps
+    // its stream order and, with one rate, its plain uniform launch).
+    static bool lengths_ragged(const int32_t* h_len, int32_t n_streams) {
+        if (!h_len || n_streams < 8) return false;
+        int32_t lo = h_len[0], hi = h_len[0];
+        for (int32_t s = 1; s < n_streams; s++) { lo = std::min(lo, h_len[s]); hi = std::max(hi, h_len[s]); }
+        return hi > 0 && (int64_t)lo * 4 < (int64_t)hi * 3;
+    }
+
     // host part: buckets and permutation (stable inside a bucket: ascending stream number)
-    void bucket(const int32_t* h_bf, int32_t n_streams) {
+    void bucket(const int32_t* h_bf, int32_t n_streams, const int32_t* h_len = nullptr) {
         n = n_streams;
+        by_length = lengths_ragged(h_len, n_streams) && !std::getenv("AFSK_GROUP_NO_LENGTH_SORT");
         std::vector<int32_t> count(AFSK_SYNC_WINDOW / 2 + 1, 0);    // slot 0 = every invalid value
         auto slot = [](int32_t bf) { return valid_bf(bf) ? bf : 0; };
         for (int32_t s = 0; s < n; s++) count[(size_t)slot(h_bf[s])]++;
@@ -635,8 +652,15 @@ struct GroupPlan {
         }
         h_upload.resize(2 * (size_t)n);
         const int32_t window = sort_window();
+        // longest first inside [b, e) of the index list (one bucket of one window)
+        auto by_len = [&](size_t b, size_t e) {
+            if (by_length && e - b > 1)
+                std::stable_sort(h_upload.begin() + (ptrdiff_t)b, h_upload.begin() + (ptrdiff_t)e,
+                                 [&](int32_t x, int32_t y) { return h_len[x] > h_len[y]; });
+        };
         if (window <= 0 || window >= n) {
             for (int32_t s = 0; s < n; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+            for (const Group& g : groups) by_len((size_t)g.first, (size_t)g.first + (size_t)g.count);
         } else {
             // bucket order INSIDE windows of `window` consecutive streams (see sort_window)
             std::vector<int32_t> wc(count.size());
@@ -648,6 +672,8 @@ struct GroupPlan {
                 size_t run = at;
                 for (int32_t bf : order) { cursor[(size_t)bf] = (int32_t)run; run += (size_t)wc[(size_t)bf]; }
                 for (int32_t s = w0; s < w1; s++) h_upload[(size_t)cursor[(size_t)slot(h_bf[s])]++] = s;
+                run = at;
+                for (int32_t bf : order) { by_len(run, run + (size_t)wc[(size_t)bf]); run += (size_t)wc[(size_t)bf]; }
                 at = run;
             }
         }
@@ -693,6 +719,7 @@ struct GroupPlan {
         if (groups.size() == 1 && groups[0].bf > 0) {
             a.bit_frames = nullptr;
             a.uniform_bit_frames = groups[0].bf;
+            a.stream_index = by_length ? d_index : nullptr;      // one rate, ragged lengths: the uniform kernel walks the list
             return afsk::launch_demod_uniform(a, stream);
         }
         a.bit_frames = d_bf;
@@ -823,6 +850,11 @@ int afsk_demod_batch_uniform(const int16_t* samples, const int64_t* stream_offse
 struct afsk_group_plan { GroupPlan p; };
 
 int afsk_group_plan_create(const int32_t* bit_frames_host, int32_t n_streams, afsk_group_plan** out_plan) {
+    return afsk_group_plan_create_ragged(bit_frames_host, nullptr, n_streams, out_plan);
+}
+
+int afsk_group_plan_create_ragged(const int32_t* bit_frames_host, const int32_t* stream_len_host, int32_t n_streams,
+                                  afsk_group_plan** out_plan) {
     if (!out_plan) return fail(AFSK_E_INVALID_ARG, "null pointer argument");
     *out_plan = nullptr;
     if (n_streams < 0) return fail(AFSK_E_INVALID_ARG, "negative size");
@@ -830,7 +862,7 @@ int afsk_group_plan_create(const int32_t* bit_frames_host, int32_t n_streams, af
     if (int rc = require_device()) return rc;
     return no_throw([&] {
         std::unique_ptr<afsk_group_plan> pl(new afsk_group_plan());
-        pl->p.bucket(bit_frames_host, n_streams);
+        pl->p.bucket(bit_frames_host, n_streams, stream_len_host);
         hipError_t e = pl->p.materialise(nullptr, nullptr);
         if (e != hipSuccess) return hip_fail(e, "afsk_group_plan_create (index list)");
         *out_plan = pl.release();
@@ -887,7 +919,7 @@ int afsk_demod_batch_grouped(const afsk_group_plan* plan, const int16_t* samples
 // The host entries see the bit_frames array: one value for all streams -> the uniform kernel;
 // several -> the grouped dispatch (index list + bit_frames live in `index_storage`, 2 n int32 of the
 // caller's device scratch; `keep` owns the side streams until the caller has synchronised).
-static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples, const int64_t* stream_offset,
+static int demod_device_auto(const int32_t* h_bit_frames, const int32_t* h_stream_len, const int16_t* samples, const int64_t* stream_offset,
                              const int32_t* stream_len, const int32_t* d_bit_frames, int32_t amp_end_threshold,
                              int32_t n_streams, uint8_t* out_bytes, int32_t out_stride, int32_t* out_nbytes,
                              int32_t* out_nbits, int32_t* out_clock_idx, int32_t* out_term_frame,
@@ -896,13 +928,14 @@ static int demod_device_auto(const int32_t* h_bit_frames, const int16_t* samples
     (void)d_bit_frames;
     bool same = true;
     for (int32_t s = 1; s < n_streams && same; s++) same = h_bit_frames[s] == h_bit_frames[0];
-    if (same)
+    // (one rate but ragged lengths: the plan, whose walk takes the longest streams first -- GroupPlan::bucket)
+    if (same && !GroupPlan::lengths_ragged(h_stream_len, n_streams))
         return afsk_demod_batch_uniform(samples, stream_offset, stream_len, h_bit_frames[0], amp_end_threshold,
                                         n_streams, out_bytes, out_stride, out_nbytes, out_nbits, out_clock_idx,
                                         out_term_frame, out_status, nullptr, nullptr, 0, stream);
     if (int rc = require_device()) return rc;
     keep.reset(new GroupPlan());
-    keep->bucket(h_bit_frames, n_streams);
+    keep->bucket(h_bit_frames, n_streams, h_stream_len);
     hipError_t e = keep->materialise(index_storage, stream);
     if (e != hipSuccess) return hip_fail(e, "grouped dispatch (index list)");
     afsk::DemodArgs a;
@@ -972,7 +1005,7 @@ static int demod_batch_host_impl(const int16_t* samples, int64_t total_samples,
              "H2D stream index");
     {
         int32_t* i32 = (int32_t*)(d_all + o_out);
-        rc = demod_device_auto(bit_frames, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+        rc = demod_device_auto(bit_frames, stream_len, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
                                (const int32_t*)(d_all + o_meta + n * 8),
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,
@@ -1112,7 +1145,7 @@ static int demod_streams_host_impl(const int16_t* const* streams, const int32_t*
              "H2D stream index");
     {
         int32_t* i32 = (int32_t*)(d_all + o_out);
-        rc = demod_device_auto(bit_frames, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
+        rc = demod_device_auto(bit_frames, stream_len, (const int16_t*)d_all, (const int64_t*)(d_all + o_meta),
                                (const int32_t*)(d_all + o_meta + n * 8),
                                (const int32_t*)(d_all + o_meta + n * 12), amp_end_threshold, n_streams,
                                (uint8_t*)(d_all + o_out + n * 20), out_stride, i32, i32 + n, i32 + 2 * n,

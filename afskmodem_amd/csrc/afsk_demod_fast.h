@@ -110,12 +110,12 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     const int32_t NR = (K + SPR - 1) / SPR;
     const uint32_t amp_thr =
         (uint32_t)(amp_end < 0 ? 0 : (amp_end > 40000 ? 40000 : amp_end)) * (uint32_t)BF;
-    // r6: the stream is re-based on the clock index (FastRing::rebase): symbol 0 sits at a 16-byte-aligned ring byte
-    // whatever ci is, so every stream runs the aligned round loops (until r5: a re-aligning copy of each, and no tail
-    // hint, for the 7 of 8 arbitrary clock indices with (2 * ci) & 15 != 0)
+    // r6: the stream is re-based on the clock index (FastRing::rebase): symbol 0 sits at a 16-byte-aligned ring byte, or
+    // 2 bytes past one when ci is odd -- two forms of every round loop instead of a re-aligning copy with seven shifts
+    // behind a switch, and the tail hint for every stream (until r5: none when (2 * ci) & 15 != 0)
     const int byte0 = fr.template rebase<(FLAGS & 4) ? 0 : 2>(xs, len, 2 * ci);   // ring byte of symbol 0
-    // Tail hint (see kProbes): for large launches (a second copy of each round loop, so that streams without the hint
-    // run exactly the code they ran before).  The UNIFORM kernels of
+    const bool odd = (byte0 & 2) != 0;
+    // Tail hint (see kProbes): the large-launch kernels (BIG), for every stream.  The UNIFORM kernels of
     // bit_frames 4 / 8 take it from kHintMinStreamsShort4 / 8 streams on (at 4096 streams it costs them 3 %).
     // (Until r5 those two went without it inside the per-stream kernel -- five- and ten-slice rounds, short of scalar
     // registers: with the r5 build the spills are gone and the hint is worth 8 % there: profiles/r5_exp18_*.)
@@ -134,10 +134,12 @@ __device__ __forceinline__ void demod_stream_fast(const int16_t* xs, int32_t len
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + kBitBufOffset);
     RxDeferred rd;
     rxd_init(rd);
+    // (a BIG kernel is only ever launched with the hint on -- launch_demod / launch_demod_uniform pick it by the same
+    // stream count -- so it holds the hinted forms alone, a small-launch kernel the plain ones)
 #define AFSK_ROUNDS(FN)                                                                                              \
     do {                                                                                                             \
-        if (BIG && hinted) FN<BF, FLAGS, true>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
-        else FN<BF, FLAGS, false>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);   \
+        if (odd) FN<BF, FLAGS, true, BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride); \
+        else FN<BF, FLAGS, false, BIG>(fr, byte0, K, NR, amp_thr, rd, words, out_row, out_stride, margins, mstride);  \
     } while (0)
     if constexpr (GP) AFSK_ROUNDS(gp_rounds);
     else if constexpr (WM) AFSK_ROUNDS(wm_rounds);

@@ -31,6 +31,13 @@
 
 #include "afsk_kernels.h"
 
+// gfx950 (MI355X) only: LDS-DMA (buffer_load ... lds, dwordx4), DPP row_bcast, SDWA with an SGPR destination, and
+// inline asm whose hand-placed wait states follow gfx940 / gfx950's VALU-SGPR hazard rules (afsk_demod_phasec.h,
+// afsk_demod_rounds_multi.h).  build.sh refuses any other AFSK_ARCH; this stops a direct hipcc call as well.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the afsk demod kernels are gfx950 code (see build.sh)"
+#endif
+
 namespace afsk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -356,8 +363,10 @@ __global__ __launch_bounds__(64 * WPB) void demod_uniform_kernel_t(DemodArgs a) 
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WPB * kFastWaveLdsProduct];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = xcd_block((int)blockIdx.x, (int)gridDim.x) * WPB + wave;
-    if (s >= a.n_streams) return;
+    const int w = xcd_block((int)blockIdx.x, (int)gridDim.x) * WPB + wave;
+    if (w >= a.n_streams) return;
+    // a ragged one-rate batch walks a length-sorted list of its streams (r6: GroupPlan::bucket, afsk_capi.hip)
+    const int s = a.stream_index ? __builtin_amdgcn_readfirstlane(a.stream_index[w]) : w;
     process_uniform_stream<BF, FLAGS, BIG>(a, s, lds_all + wave * kFastWaveLdsProduct, lane);
 }
 

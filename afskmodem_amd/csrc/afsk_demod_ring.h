@@ -141,28 +141,31 @@ struct FastRing {
     // aligned to run at speed (gfx950 executes misaligned ds_read_b128 several times slower), so until r5 a stream
     // with (2 * ci) & 15 != 0 -- 7 of 8 captures that do not start on the first sample of the training sequence, e.g.
     // every burst the live gate cuts at a 2048-sample block boundary (ref:299-319) -- ran a second form of every round
-    // loop: one LDS read more per piece and a v_alignbyte per dword, in every round, and no tail hint (-9 % at 1200
-    // baud: profiles/r6_exp1_lead_baseline.txt).  Now the stream is RE-BASED once, right after phase A, by
-    // S = (2 * ci) & 15 bytes:
+    // loop: one LDS read more per piece and a v_alignbyte per dword behind a seven-way switch, in every round, and no
+    // tail hint (-9 % at 1200 baud: profiles/r6_exp1_lead_baseline.txt).  Now the stream is RE-BASED once, right after
+    // phase A, by S = (2 * ci) & 12 bytes -- the whole dwords of the misalignment:
     //   * the ring contents from the clock index's chunk on move down by S bytes in place (aligned 16-byte reads of a
-    //     lane's own and its neighbour's 16 bytes, S / 4 as a register renaming and S % 4 = 2 as one v_alignbyte per dword,
-    //     one 16-byte write; chunk by chunk, front to back: a chunk's reads reach 16 bytes into the next one, which is
-    //     not written before the next iteration);
+    //     lane's own and its neighbour's 16 bytes, a register renaming, one 16-byte write; chunk by chunk, front to back:
+    //     a chunk's reads reach 16 bytes into the next one, which is not written before the next iteration);
     //   * the last S bytes of slot 15 -- stream bytes [16384, 16384 + S), never requested -- arrive by a four-lane
     //     dword LDS-DMA into the last 16 bytes of the ring;
     //   * the buffer descriptor moves up by S bytes (base + S, num_records - S): chunk c is now stream bytes
     //     [S + 1024 c, S + 1024 (c + 1)), range checks and tail clipping as before.
-    // From here on symbol 0 sits at the 16-byte-aligned ring byte 2 * ci - S and every stream runs the aligned round
-    // loops -- with the tail hint, whose probes are requested after this.
+    // From here on symbol 0 sits at ring byte 2 * ci - S = a multiple of 16, or -- an odd clock index -- 2 bytes past one,
+    // and every stream runs one of TWO forms of its round loop (ODD = the shift by one sample in registers), both with
+    // the tail hint, whose probes are requested after this.
+    // Why not the last 2 bytes as well: moving the descriptor by an odd number of samples makes every LDS-DMA request
+    // 2-byte-aligned in memory, and those run at well under half speed -- 65536 x 1200 baud with every clock index odd:
+    // 1064 us against 855 us for S = 4 / 8 / 12 and 848 us for S = 0 (profiles/r6_exp3_rebase_by_shift.txt); the
+    // LDS-DMA cannot place data at half a dword in LDS either.
     // Wait-count invariant: the four-lane request completes chunk 15, so it is the one request after which the auxiliary
     // count restarts (warm_ops = 0: the warming requests in front of it are older than it; counting them no longer only
     // makes a wait for a chunk below 15 wait for up to two landed requests more).  A wait for chunk 15 then allows
     // exactly the requests issued behind this one to be outstanding, and the fixed-schedule immediates hold as before
     // (a round that reads chunk 15 has at least 15 - R younger chunk requests behind it).
-    template <int S>
+    template <int A>                                           // A = S / 4 dwords
     __device__ __forceinline__ void shift_down(int c0) {
-        static_assert(S > 0 && S < 16 && S % 2 == 0, "an even number of bytes below 16");
-        constexpr int A = S / 4, B = S % 4;
+        static_assert(A >= 1 && A <= 3, "one to three dwords");
         for (int c = c0; c < kRingChunks; c++) {
             uint8_t* p = ring + 1024 * c + 16 * lane;
             const u32x4 lo4 = *reinterpret_cast<const u32x4*>(p);
@@ -170,10 +173,7 @@ struct FastRing {
             const uint32_t W[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             u32x4 o;
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                if constexpr (B == 0) o[d] = W[d + A];
-                else o[d] = __builtin_amdgcn_alignbyte(W[d + A + 1], W[d + A], B);
-            }
+            for (int d = 0; d < 4; d++) o[d] = W[d + A];
             wave_lds_sync();                                   // every lane has read before any lane writes
             *reinterpret_cast<u32x4*>(p) = o;
             wave_lds_sync();
@@ -182,20 +182,16 @@ struct FastRing {
     // xs / len: the stream as the caller gave it; byte0 = 2 * ci.  Returns byte0 - S, the re-based ring byte of symbol 0.
     template <int AUX>
     __device__ __forceinline__ int rebase(const int16_t* xs, int32_t len, int byte0) {
-        const int S = byte0 & 15;
+        const int S = byte0 & 12;
         if (S == 0) return byte0;
         // phase A waited for chunks 0..7 only: everything that moves must have landed (and nothing may land on top of
         // moved bytes later) -- all 16 chunk requests; the warming requests behind them write to their dummy area
         wait_exact<0>(kRingChunks - 1);
         const int c0 = byte0 >> 10;                            // chunks below the clock index are free: not moved
         switch (S) {
-            case 2: shift_down<2>(c0); break;
-            case 4: shift_down<4>(c0); break;
-            case 6: shift_down<6>(c0); break;
-            case 8: shift_down<8>(c0); break;
-            case 10: shift_down<10>(c0); break;
-            case 12: shift_down<12>(c0); break;
-            default: shift_down<14>(c0); break;
+            case 4: shift_down<1>(c0); break;
+            case 8: shift_down<2>(c0); break;
+            default: shift_down<3>(c0); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the moved bytes are in place before the DMA below can land
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const uint8_t*>(xs) + S), 0, len * 2 - S, 0x00020000);

@@ -102,15 +102,17 @@ __device__ __forceinline__ void fast_round_compute(const uint32_t (&x)[20], int 
     }
 }
 
-// The round loop.  byte0 -- the ring byte of symbol 0 -- is a multiple of 16 (FastRing::rebase, r6): five aligned
-// ds_read_b128 feed the arithmetic directly.  (Until r5 streams whose clock index was not a multiple of 8 samples ran a
-// second form: six reads + v_alignbyte per dword, every round.)
-template <int BF, int FLAGS, bool HINTED>
+// The round loop.  byte0 -- the ring byte of symbol 0 after FastRing::rebase (r6) -- is a multiple of 16 (ODD = false:
+// five aligned ds_read_b128 feed the arithmetic directly) or, for an odd clock index, 2 bytes past one (ODD = true: six
+// aligned reads, shifted down by the one sample with a v_alignbyte per dword -- neither the LDS-DMA nor an LDS read moves
+// data by half a dword at speed).  (Until r5: seven shifts behind a switch in every round, and no tail hint for them.)
+template <int BF, int FLAGS, bool ODD, bool HINTED>
 __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                             uint32_t amp_thr, RxDeferred& rd,
                                             unsigned long long* words, uint8_t* out_row,
                                             int out_stride, int32_t* margins, int32_t mstride) {
     constexpr int SPR = 2560 / BF;                                // symbols per 5 KiB round
+    constexpr bool ALIGNED = !ODD;
     const int lane = fr.lane;
     for (int r = 0; r < NR; r++) {
         // bytes [byte0 + 5120 r, byte0 + 5120 (r+1)) must have landed: at most 6 chunks
@@ -119,13 +121,13 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
         int32_t Kr = K;                    // symbols this round may use (fewer: a partial round, see holding_wait)
         bool partial = false;
         RxDeferred saved;
-        const int last = byte0 + 5120 * r + 5119;                                      // last byte read
+        const int last = byte0 + 5120 * r + 5119 + (ALIGNED ? 0 : 16);                 // last byte read
         if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed 5-chunks-per-round schedule
             Kr = fr.template holding_wait<(FLAGS & 4) ? 0 : 2>(last, K, r * SPR, byte0, 2 * BF, partial);
             if (partial) saved = rd;
         } else {
             fr.template wait_fixed<10>(((byte0 + 5120 * r) >> 10) + 5);
-            if constexpr (HINTED) fr.template eval_probes<fine_probes(5120)>(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, 0, 2 * BF);
+            if constexpr (HINTED) fr.template eval_probes<fine_probes(5120)>(((byte0 + 5120 * r) >> 10) + 5, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : 16, 2 * BF);
         }
         uint32_t x[20];
         const int rb = (byte0 + 5120 * r) & (kRingBytes - 1);         // wave-uniform
@@ -136,26 +138,51 @@ __device__ __forceinline__ void fast_rounds(FastRing& fr, int byte0, int32_t K, 
 #pragma unroll
             for (int piece = 0; piece < 2; piece++) {
                 const int pb = rb + 2560 * piece + 40 * lane;
+                if constexpr (ALIGNED) {
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((pb + 8 * j) & (kRingBytes - 1)));
-                    x[10 * piece + 2 * j] = t2[0]; x[10 * piece + 2 * j + 1] = t2[1];
+                    for (int j = 0; j < 5; j++) {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((pb + 8 * j) & (kRingBytes - 1)));
+                        x[10 * piece + 2 * j] = t2[0]; x[10 * piece + 2 * j + 1] = t2[1];
+                    }
+                } else {
+                    const int ab = pb & ~7;
+                    uint32_t W[12];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(fr.ring + ((ab + 8 * j) & (kRingBytes - 1)));
+                        W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
+                    }
+                    uint32_t y[10];
+                    realign_n<2, 12, 10>(W, y);
+#pragma unroll
+                    for (int d = 0; d < 10; d++) x[10 * piece + d] = y[d];
                 }
             }
-        } else if (rb + 5120 <= kRingBytes) {                           // no wrap in this round
-            const uint8_t* src = fr.ring + rb + 80 * lane;
+        } else if constexpr (ALIGNED) {
+            if (rb + 5120 <= kRingBytes) {                              // no wrap in this round
+                const uint8_t* src = fr.ring + rb + 80 * lane;
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
-                x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+                for (int j = 0; j < 5; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(src + 16 * j);
+                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+                }
+            } else {
+                const int pb = rb + 80 * lane;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((pb + 16 * j) & (kRingBytes - 1)));
+                    x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+                }
             }
         } else {
-            const int pb = rb + 80 * lane;
+            const int ab = (rb + 80 * lane) & ~15;
+            uint32_t W[24];
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((pb + 16 * j) & (kRingBytes - 1)));
-                x[4 * j] = t4[0]; x[4 * j + 1] = t4[1]; x[4 * j + 2] = t4[2]; x[4 * j + 3] = t4[3];
+            for (int j = 0; j < 6; j++) {
+                const u32x4 t4 = *reinterpret_cast<const u32x4*>(fr.ring + ((ab + 16 * j) & (kRingBytes - 1)));
+                W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
             }
+            realign<2>(W, x);
         }
         // the reads above have returned (their values are in x): refill the 5 chunks this
         // round consumed right away, before the arithmetic

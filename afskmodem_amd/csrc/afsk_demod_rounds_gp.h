@@ -17,7 +17,8 @@ namespace afsk {
 // serves both correlators: SAD against lo = 65535 * n - SAD against hi) and two tail slots with per-lane
 // template dwords (the second one masked off for lanes with NB + 1 dwords).  All 64 lanes work for every
 // bit_frames; rounds are 3.8 - 8 KiB of whole symbols with the watermark refill, linear reads into the
-// mirror behind the ring, dword reads (the stream is re-based on the clock index: FastRing::rebase).
+// mirror behind the ring, dword reads at the aligned address at or below a piece (shifted by 2 bytes in registers for an
+// odd clock index; everything else of a clock index is taken out by FastRing::rebase).
 template <int BF>
 struct GpGeom {
     static constexpr int Q = BF / 4, D = BF / 2;
@@ -84,7 +85,8 @@ __device__ __forceinline__ uint64_t compress_bits_last(uint64_t x) {
     else return compress_bits<LPS>(x >> (LPS - 1));
 }
 
-template <int BF, int FLAGS, bool HINTED>
+// ODD: byte0 is 2 bytes past a multiple of 16 (an odd clock index after FastRing::rebase), else a multiple of 16.
+template <int BF, int FLAGS, bool ODD, bool HINTED>
 __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                           uint32_t amp_thr, RxDeferred& rd,
                                           unsigned long long* words, uint8_t* out_row,
@@ -124,31 +126,41 @@ __device__ __forceinline__ void gp_rounds(FastRing& fr, int byte0, int32_t K, in
                     *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
             wave_lds_sync();
         }
-        // The reads are typed by what is KNOWN about a piece's address (byte0 is a multiple of 16 since r6 --
-        // FastRing::rebase; until then an odd clock index put every piece 2 bytes into a dword), because the compiler
-        // merges adjacent dword reads into 8- and 16-byte reads and the hardware executes those several times slower at
-        // addresses that are not that aligned (5 us per 4096 streams at 240 / 160 / 120 / 80 baud, 15 % at 32768 x 160
-        // baud): geometries whose pieces all start on 16- (8-) byte multiples of the round read 16 (8) bytes at a time
-        // (bit_frames 192, 384, 640 ...: 6 % faster than dword pairs); everything else reads dword pairs (ds_read2_b32
+        // The piece is read from the dword-aligned address at or below its first byte (an odd clock index puts
+        // it 2 bytes into a dword) and shifted in registers.  The reads are typed by what is KNOWN about that
+        // address, because the compiler merges adjacent dword reads into 8- and 16-byte reads and the hardware
+        // executes those several times slower at addresses that are not that aligned (5 us per 4096 streams at
+        // 240 / 160 / 120 / 80 baud, 15 % at 32768 x 160 baud): geometries whose pieces all start on 16- (8-)
+        // byte multiples of the round read 16 (8) bytes at a time when the clock index allows it (bit_frames
+        // 192, 384, 640 ...: 6 % faster than dword pairs); everything else reads dword pairs (ds_read2_b32
         // needs 4-byte alignment only).
-        const uint8_t* src = fr.ring + ((rb + piece_byte) & (kRingBytes - 1));
+        constexpr int sh = ODD ? 2 : 0;                               // 2 for an odd clock index
+        const uint8_t* src = fr.ring + (((rb + piece_byte) & (kRingBytes - 1)) - sh);
         constexpr int PALIGN = G::PALIGN;
-        constexpr int NW = NB + 2;
-        uint32_t x[NW];
-        if constexpr (PALIGN >= 8) {
+        constexpr int NW = NB + 3;                                    // one dword more for the shifted form
+        uint32_t W[NW];
+        if constexpr (PALIGN >= 8) {                                  // (src = the 16-byte-aligned ring byte of the round + a multiple of PALIGN)
             constexpr int VW = PALIGN / 4;                            // dwords per read
             typedef uint32_t uvec __attribute__((ext_vector_type(VW), aligned(PALIGN)));
 #pragma unroll
             for (int v = 0; v < NW / VW; v++) {
                 const uvec t = *reinterpret_cast<const uvec*>(src + PALIGN * v);
 #pragma unroll
-                for (int u = 0; u < VW; u++) x[VW * v + u] = t[u];
+                for (int u = 0; u < VW; u++) W[VW * v + u] = t[u];
             }
 #pragma unroll
-            for (int d = (NW / VW) * VW; d < NW; d++) x[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+            for (int d = (NW / VW) * VW; d < NW; d++) W[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
         } else {
 #pragma unroll
-            for (int d = 0; d < NW; d++) x[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+            for (int d = 0; d < NW; d++) W[d] = *reinterpret_cast<const uint32_t*>(src + 4 * d);
+        }
+        uint32_t x[NB + 2];
+        if constexpr (sh == 0) {
+#pragma unroll
+            for (int d = 0; d < NB + 2; d++) x[d] = W[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB + 2; d++) x[d] = __builtin_amdgcn_alignbyte(W[d + 1], W[d], 2);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         if (!(HINTED && partial)) fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);

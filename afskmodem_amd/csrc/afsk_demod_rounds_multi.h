@@ -40,16 +40,20 @@ struct MultiGeom {
     static_assert(!valid || (SPL * BF == 8 * R && PB % RW == 0 && R + 1 < kRingChunks), "round geometry");
 };
 
-template <int BF, int FLAGS, bool HINTED>
+// ODD: byte0 is 2 bytes past a multiple of 16 (an odd clock index after FastRing::rebase): one read unit more per
+// piece, shifted down in registers; otherwise byte0 is a multiple of 16.
+template <int BF, int FLAGS, bool ODD, bool HINTED>
 __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                              uint32_t amp_thr, RxDeferred& rd,
                                              unsigned long long* words, uint8_t* out_row,
                                              int out_stride, int32_t* margins, int32_t mstride) {
     using MG = MultiGeom<BF>;
     constexpr int R = MG::R, SPL = MG::SPL, PB = MG::PB, RW = MG::RW, NO = MG::NO, SPR = MG::SPR;
+    constexpr bool ALIGNED = !ODD;
     constexpr int Q = BF / 4, H = BF / 2;
     constexpr uint32_t FULL = 65535u;
-    constexpr int NR_READS = PB / RW;                          // reads per piece (byte0 is a multiple of 16: FastRing::rebase)
+    constexpr int NR_READS = PB / RW;                          // reads per piece when aligned
+    constexpr int DW = RW / 4;                                 // dwords per read
     const int lane = fr.lane;
     // (bit_frames 16 / 32 / 64: the lanes of a ds_read_b128 group, 32 / 64 / 128 bytes apart, collide on bank quads -- 2-,
     // 4-, 8-way.  A conflict-free read order was measured for bit_frames 16 (second half first in half the lanes, space
@@ -60,19 +64,19 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
         int32_t Kr = K;                    // symbols this round may use (fewer: a partial round, see holding_wait)
         bool partial = false;
         RxDeferred saved;
-        const int last = byte0 + 1024 * R * (r + 1) - 1;                                 // last byte read
+        const int last = byte0 + 1024 * R * (r + 1) - 1 + (ALIGNED ? 0 : RW);            // last byte read
         if (HINTED && fr.hint_holding()) { // the tail hint has stopped the fixed R-chunks-per-round schedule
             Kr = fr.template holding_wait<(FLAGS & 4) ? 0 : 2>(last, K, r * SPR, byte0, PB, partial);
             if (partial) saved = rd;
         } else {
             fr.template wait_fixed<kRingChunks - 1 - R>(((byte0 + 1024 * R * r) >> 10) + R);
-            if constexpr (HINTED) fr.template eval_probes<fine_probes(1024 * R)>(((byte0 + 1024 * R * r) >> 10) + R, amp_thr / (uint32_t)BF, byte0, 0, PB);
+            if constexpr (HINTED) fr.template eval_probes<fine_probes(1024 * R)>(((byte0 + 1024 * R * r) >> 10) + R, amp_thr / (uint32_t)BF, byte0, ALIGNED ? 0 : RW, PB);
         }
         uint32_t x[SPL * NO];
         const int rb = (byte0 + 1024 * R * r) & (kRingBytes - 1);      // wave-uniform
         // a round that does not cross the ring end (two of three) reads at constant offsets from ONE lane address
         // (r5: the masked form costs three VALU instructions per read for the wrap that mostly does not happen)
-        const bool nowrap = rb + 1024 * R <= kRingBytes;               // wave-uniform
+        const bool nowrap = ALIGNED && rb + 1024 * R <= kRingBytes;    // wave-uniform
         auto read_piece = [&](const uint8_t* p, int piece, int j) {
             if constexpr (RW == 16) {
                 const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
@@ -94,9 +98,29 @@ __device__ __forceinline__ void multi_rounds(FastRing& fr, int byte0, int32_t K,
 #pragma unroll
         for (int piece = 0; piece < SPL; piece++) {
             const int pb = rb + 64 * PB * piece + PB * lane;
+            if constexpr (ALIGNED) {
 #pragma unroll
-            for (int j = 0; j < NR_READS; j++)
-                read_piece(fr.ring + ((pb + RW * j) & (kRingBytes - 1)), piece, j);
+                for (int j = 0; j < NR_READS; j++)
+                    read_piece(fr.ring + ((pb + RW * j) & (kRingBytes - 1)), piece, j);
+            } else {
+                const int ab = pb & ~(RW - 1);
+                uint32_t W[NO + DW];
+#pragma unroll
+                for (int j = 0; j < NR_READS + 1; j++) {
+                    const uint8_t* p = fr.ring + ((ab + RW * j) & (kRingBytes - 1));
+                    if constexpr (RW == 16) {
+                        const u32x4 t4 = *reinterpret_cast<const u32x4*>(p);
+                        W[4 * j] = t4[0]; W[4 * j + 1] = t4[1]; W[4 * j + 2] = t4[2]; W[4 * j + 3] = t4[3];
+                    } else {
+                        const u32x2 t2 = *reinterpret_cast<const u32x2*>(p);
+                        W[2 * j] = t2[0]; W[2 * j + 1] = t2[1];
+                    }
+                }
+                uint32_t y[NO];
+                realign_n<2, NO + DW, NO>(W, y);
+#pragma unroll
+                for (int d = 0; d < NO; d++) x[NO * piece + d] = y[d];
+            }
         }
         }
         const int k0 = r * SPR;

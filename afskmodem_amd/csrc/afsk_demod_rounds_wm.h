@@ -39,7 +39,9 @@ struct WmGeom {
                   "round geometry");
 };
 
-template <int BF, int FLAGS, bool HINTED>
+// ODD: byte0 is 2 bytes past a multiple of 16 (an odd clock index after FastRing::rebase): the reads start at the
+// aligned address below and take one unit more, shifted down in registers; otherwise byte0 is a multiple of 16.
+template <int BF, int FLAGS, bool ODD, bool HINTED>
 __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, int32_t NR,
                                           uint32_t amp_thr, RxDeferred& rd,
                                           unsigned long long* words, uint8_t* out_row,
@@ -48,7 +50,9 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     constexpr int LPS = G::LPS, PL = G::PL, PB = G::PB, NO = G::NO, RW = G::RW, SPP = G::SPP, RBYTES = G::RBYTES;
     constexpr int Q = BF / 4, H = BF / 2;
     constexpr uint32_t FULL = 65535u;
-    constexpr int NW = NO;                                        // dwords a lane reads (byte0 is a multiple of 16: FastRing::rebase)
+    constexpr bool ALIGNED = !ODD;
+    constexpr int EXTRA = ALIGNED ? 0 : RW;                       // the re-aligning path reads one unit more
+    constexpr int NW = NO + EXTRA / 4;                            // dwords a lane reads
     typedef u32x4 u32x4_a16 __attribute__((aligned(16)));
     typedef u32x2 u32x2_a8 __attribute__((aligned(8)));
     const int lane = fr.lane;
@@ -59,7 +63,7 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
     // template, one sum): read j takes chunk (j + r) & 3 of quarter (j >> 2) ^ sw, with r = lane bits 1-2 and
     // sw = lane bit 3 -- the 16 lanes of a group then touch 16 different bank quads -- and the two quarter sums
     // are exchanged in the lanes with sw set.
-    constexpr bool SWZ = BF == 128;
+    constexpr bool SWZ = ALIGNED && BF == 128;
     int swz_off[SWZ ? 8 : 1];
     const bool swz_sw = SWZ && ((lane >> 3) & 1);
     if constexpr (SWZ) {
@@ -67,17 +71,17 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
         for (int j = 0; j < 8; j++)
             swz_off[j] = 16 * (((j & 3) + ((lane >> 1) & 3)) & 3) + 64 * ((j >> 2) ^ ((lane >> 3) & 1));
     }
-    int pos = byte0;                                              // stream byte where this round's reads start
+    int pos = byte0 & ~(RW - 1);                                  // stream byte where this round's reads start
     for (int r = 0; r < NR; r++, pos += RBYTES) {
-        const int last = pos + RBYTES - 1;                        // last stream byte this round reads
+        const int last = pos + RBYTES + EXTRA - 1;                // last stream byte this round reads
         bool partial;                                             // (a partial round: see FastRing::holding_wait)
         RxDeferred saved;
-        const int32_t Kr = fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos, K, r * SPP, byte0, 2 * BF, partial);
+        const int32_t Kr = fr.template wait_round<(FLAGS & 4) ? 0 : 2, RBYTES + EXTRA, HINTED>(pos, K, r * SPP, byte0, 2 * BF, partial);
         if (HINTED && partial) saved = rd;
         const int32_t mlim = Kr < mstride ? Kr : mstride;         // soft output rows hold symbols [0, mlim)
-        if constexpr (HINTED) fr.template eval_probes<fine_probes(RBYTES)>(last >> 10, amp_thr / (uint32_t)BF, byte0, 0, 2 * BF);
+        if constexpr (HINTED) fr.template eval_probes<fine_probes(RBYTES)>(last >> 10, amp_thr / (uint32_t)BF, byte0 & ~(RW - 1), EXTRA, 2 * BF);
         const int rb = pos & (kRingBytes - 1);                    // wave-uniform
-        if (rb + RBYTES > kRingBytes) {                           // a piece runs past the ring end: refresh the mirror
+        if (rb + RBYTES + EXTRA > kRingBytes) {                   // a piece runs past the ring end: refresh the mirror
             if (lane < kMirrorBytes / 16)
                 *reinterpret_cast<u32x4*>(fr.ring + kRingBytes + 16 * lane) =
                     *reinterpret_cast<const u32x4*>(fr.ring + 16 * lane);
@@ -101,8 +105,12 @@ __device__ __forceinline__ void wm_rounds(FastRing& fr, int byte0, int32_t K, in
             }
         }
         uint32_t x[NO];
+        if constexpr (ALIGNED) {
 #pragma unroll
-        for (int d = 0; d < NO; d++) x[d] = W[d];
+            for (int d = 0; d < NO; d++) x[d] = W[d];
+        } else {
+            realign_n<2, NW, NO>(W, x);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers: refill right away
         // every chunk wholly below the next round's first byte is free
         if (!(HINTED && partial)) fr.template refill_round<(FLAGS & 4) ? 0 : 2, RBYTES, HINTED>(pos);

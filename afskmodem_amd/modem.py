@@ -400,8 +400,9 @@ class Receiver:
         samples, off, ln, max_len = batch.load_wav_batch(names)
         self.check_decodable(max_len)
         stride = batch.out_stride_for(max_len, self.__bit_frames)
+        # (files of different lengths: the host-side lengths let the launch take the longest streams first)
         res = batch.demod_batch(samples, off, ln, self.__bit_frames, self.__amp_end_threshold,
-                                out_stride=stride)
+                                out_stride=stride, stream_len_host=ln.cpu().numpy())
         torch.cuda.synchronize()
         return [d.decode("utf-8") if (string and d != b"") else d for d in res.payloads()]
 
@@ -425,7 +426,7 @@ class Receiver:
         self.check_decodable(int(b_len.max()))
         stride = batch.out_stride_for(int(b_len.max()), self.__bit_frames)
         res = batch.demod_batch(samples, b_off, b_len, self.__bit_frames, self.__amp_end_threshold,
-                                out_stride=stride)
+                                out_stride=stride, stream_len_host=b_len.cpu().numpy())
         torch.cuda.synchronize()
         for o, data in zip(owner.cpu().tolist(), res.payloads()):
             out[o].append(data.decode("utf-8") if (string and data != b"") else data)
@@ -458,7 +459,8 @@ def load_batch(receivers, filenames, string: bool = False):
     for a in sorted(set(amp)):
         idx = np.array([i for i, v in enumerate(amp) if v == a], np.int64)
         d_idx = torch.from_numpy(idx).to(samples.device)
-        res = batch.demod_batch(samples, off[d_idx].contiguous(), ln[d_idx].contiguous(), bf[idx], a, out_stride=stride)
+        res = batch.demod_batch(samples, off[d_idx].contiguous(), ln[d_idx].contiguous(), bf[idx], a, out_stride=stride,
+                                stream_len_host=lens[idx])
         torch.cuda.synchronize()
         for i, data in zip(idx, res.payloads()):
             out[int(i)] = data.decode("utf-8") if (string and data != b"") else data

@@ -86,14 +86,14 @@ LEAD_FIXED = {}                 # name -> fixed lead (samples) instead of a per-
 LEAD_NOISE = 600                # |x| < this in the lead-in (the limiter's dead zone is 512, the squelch 14000)
 LEAD_SEED = 777
 HEADLINE = "config5"            # the headline workload at EVERY N (one weak-scaling curve)
-NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress")   # SURVEY 8(f) rows (+ the egress) as sub-records at N = 1
+NEXT_ROWS = ("f1_modulate", "f2_gate", "f3_wav_ingest", "f5_wav_egress", "f2_chain", "ragged_lengths")   # SURVEY 8(f) rows (+ the egress) as sub-records at N = 1
 RATES_ROW = "rates_4096"        # 4096 x 1 s at EVERY rate a Receiver can be built for (36 values of bit_frames)
 RATES_BIG_ROW = "rates_65536"   # the same at 65536 streams: the steady-state fraction per rate (no launch-shape quantisation)
 RATES_ROWS = {RATES_ROW: 4096, RATES_BIG_ROW: 65536}
 # what the default N = 1 run carries besides configs 2-4: the three SURVEY 8(f) rows and the steady-state per-rate
 # table.  f5_wav_egress (not a SURVEY row) and rates_4096 (launch-shape quantisation, documented and closed) are
 # measured on request: --sub f5_wav_egress,rates_4096
-DEFAULT_RIDERS = ("f1_modulate", "f2_gate", "f3_wav_ingest", RATES_BIG_ROW)
+DEFAULT_RIDERS = ("f1_modulate", "f2_gate", "f2_chain", "f3_wav_ingest", RATES_BIG_ROW)
 # 48000 / baud must divide 48000 and be a multiple of 4: 12000 ... 24 baud
 ALL_RATES = tuple(48000 // bf for bf in range(4, 2048, 4) if 48000 % bf == 0)
 BER_SNRS = (30, 25, 20, 15, 10, 7, 5, 3, 0)   # configs[3] sweep 30 -> 5 dB + two points below it
@@ -871,6 +871,9 @@ def _sub_summary(name: str, rec: dict) -> dict:
             out["match_rate"] = rec[k]
     if "roundtrip_match_rate" in rec and rec["roundtrip_match_rate"] is not None:
         out["roundtrip"] = rec["roundtrip_match_rate"]
+    for k in ("chain_ms", "ragged_over_uniform_time_per_byte_planned", "ragged_over_uniform_time_per_byte_stream_order"):
+        if k in rec:
+            out[{"chain_ms": "chain_ms", "ragged_over_uniform_time_per_byte_planned": "ragged_vs_1s", "ragged_over_uniform_time_per_byte_stream_order": "ragged_vs_1s_unplanned"}[k]] = rec[k]
     if "frac_overwrite_in_place" in (rec.get("roofline") or {}):
         out["frac_overwrite"] = rec["roofline"]["frac_overwrite_in_place"]
     if "entry" in rec:
@@ -1152,6 +1155,10 @@ def _run_rank(args, hb: Heartbeat, dog: Watchdog) -> None:
             subs["f3_wav_ingest"] = rider("f3_wav_ingest", lambda: __import__("bench_rows").measure_wav_ingest(ctx, args.wav_files))
         if "f5_wav_egress" in next_rows:
             subs["f5_wav_egress"] = rider("f5_wav_egress", lambda: __import__("bench_rows").measure_wav_egress(ctx, args.wav_files))
+        if "f2_chain" in next_rows:          # r6: gate -> burst_slots -> demod as one graph, on led-in captures
+            subs["f2_chain"] = rider("f2_chain", lambda: __import__("bench_rows").measure_gate_chain(ctx, args.next_reps))
+        if "ragged_lengths" in next_rows:    # r6, on request: a ragged batch against the same samples as 1 s streams
+            subs["ragged_lengths"] = rider("ragged_lengths", lambda: __import__("bench_rows").measure_ragged(ctx, max(3, args.next_reps // 2)))
         checkpoint("the per-rate tables")
         # (the steady-state table first: it follows the host-bound file rows, during which the GPU idles, so its 36
         # workloads start from a state closer to the headline's than after the 36 prerolls of the 4096-stream table)

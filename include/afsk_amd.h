@@ -162,6 +162,14 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
  *
  *  afsk_group_plan_create   bit_frames_host: HOST array [n].  Allocates 8 n bytes on the current device and
  *                           fills them (synchronous).
+ *  afsk_group_plan_create_ragged  (r6, an addition: ABI version unchanged) the same with stream_len_host, a HOST
+ *                           array [n] of the lengths the launches will be given (NULL = afsk_group_plan_create).  One
+ *                           wavefront decodes one stream whatever its length and a workgroup of four keeps its share of
+ *                           a CU until its longest stream ends, so when the lengths differ (shortest below 3/4 of the
+ *                           longest) the walk takes, inside every window of 4096 consecutive streams and every rate,
+ *                           the LONGEST streams first -- also for a one-rate batch, whose uniform kernel then walks the
+ *                           list.  Results do not depend on it (same outputs at the same stream numbers); lengths that
+ *                           differ from those given later only cost speed.  The host entries do this by themselves.
  *  afsk_group_plan_info     n_streams, number of buckets, and per bucket (first `cap` of them, in launch
  *                           order: largest first) its bit_frames (0 = the refused streams) and stream count;
  *                           any pointer may be NULL
@@ -171,6 +179,8 @@ int afsk_demod_batch_uniform(const int16_t *samples, const int64_t *stream_offse
  */
 typedef struct afsk_group_plan afsk_group_plan;
 int afsk_group_plan_create(const int32_t *bit_frames_host, int32_t n_streams, afsk_group_plan **out_plan);
+int afsk_group_plan_create_ragged(const int32_t *bit_frames_host, const int32_t *stream_len_host, int32_t n_streams,
+                                  afsk_group_plan **out_plan);
 int afsk_group_plan_info(const afsk_group_plan *plan, int32_t *out_n_streams, int32_t *out_n_groups,
                          int32_t *out_group_bit_frames, int32_t *out_group_count, int32_t cap);
 int afsk_group_plan_destroy(afsk_group_plan *plan);

@@ -252,9 +252,9 @@ def test_headline_workload_is_the_same_at_every_n():
     assert la.min() == 0 and la.max() == 2047 and (la[32768:32768 + 4096] == lb).all()
     assert 0.85 < float(((2 * la) & 15).astype(bool).mean()) < 0.90
     assert bench.Shard.host_leads("config5", 0, 16) is None
-    assert one["next"] == ["f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"] == list(bench.DEFAULT_RIDERS)
+    assert one["next"] == ["f1_modulate", "f2_gate", "f2_chain", "f3_wav_ingest", "rates_65536"] == list(bench.DEFAULT_RIDERS)
     # the egress mirror and the 4096-stream table are measured on request only
-    assert bench.plan(1, "", "f5_wav_egress,rates_4096")["next"] == ["f5_wav_egress", "rates_4096"]
+    assert bench.plan(1, "", "f5_wav_egress,rates_4096,ragged_lengths")["next"] == ["f5_wav_egress", "rates_4096", "ragged_lengths"]
     assert len(bench.ALL_RATES) == 36 and set((300, 1200, 2400, 100, 160, 96, 24, 12000)) <= set(bench.ALL_RATES)
     assert two["subs"] == ["config2"] and two["next"] == []
     # an explicit workload drops the riders unless --sub lists them; the next rows are never a headline

@@ -250,6 +250,93 @@ def test_group_plan_buckets(stub):
     assert stub.afsk_group_plan_destroy(h) == 0
 
 
+def _walk(stub, n):
+    """(kind, index list or None, uniform bit_frames) of the last demod launch of the stub library."""
+    idx = np.full(n, -1, np.int32)
+    ubf, nn = C.c_int32(), C.c_int32()
+    stub.afsk_stub_last_launch.restype = C.c_int
+    stub.afsk_stub_last_launch.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    kind = stub.afsk_stub_last_launch(p32(idx), n, C.byref(ubf), C.byref(nn))
+    assert nn.value == n
+    return abs(kind), (idx if kind > 0 else None), ubf.value
+
+
+def _launch_plan(stub, h, n):
+    x = np.zeros(64, np.int16); off = np.zeros(n, np.int64); ln = np.zeros(n, np.int32)
+    i32 = [np.zeros(n, np.int32) for _ in range(5)]
+    assert stub.afsk_demod_batch_grouped(h, x.ctypes.data, off.ctypes.data, ln.ctypes.data, 14000, None, 0,
+                                         *(a.ctypes.data for a in i32), None, None, 0, None) == 0
+    return _walk(stub, n)
+
+
+def test_group_plan_takes_the_longest_streams_first_when_lengths_are_ragged(stub):
+    """afsk_group_plan_create_ragged (r6): inside every window of 4096 streams and every rate bucket the walk is by
+    descending length (stable), for one rate too (the uniform kernel then walks the list); equal lengths -- or no
+    lengths -- leave the r5 plan byte for byte."""
+    rng = np.random.default_rng(8)
+    n = 10000
+    # ---- one rate, ragged lengths: uniform kernel + index list, windows of 4096, longest first, stable
+    bf = np.full(n, 40, np.int32)
+    ln = rng.integers(12000, 192001, n).astype(np.int32)
+    ln[100:200] = 96000                                                     # ties keep stream order
+    h = C.c_void_p()
+    assert stub.afsk_group_plan_create_ragged(p32(bf), p32(ln), n, C.byref(h)) == 0 and h
+    kind, idx, ubf = _launch_plan(stub, h, n)
+    assert kind == 2 and ubf == 40 and idx is not None
+    assert sorted(idx.tolist()) == list(range(n))                           # a permutation
+    for w0 in range(0, n, 4096):
+        w = idx[w0: w0 + 4096]
+        assert w.min() == w0 and w.max() == min(n, w0 + 4096) - 1          # a window holds its own streams
+        want = w0 + np.argsort(-ln[w0: w0 + 4096].astype(np.int64), kind="stable")
+        assert np.array_equal(w, want)
+    assert stub.afsk_group_plan_destroy(h) == 0
+    # ---- the same rates and lengths that do NOT differ enough: plain uniform launch, no list
+    flat = np.full(n, 48000, np.int32); flat[::7] = 40000
+    assert stub.afsk_group_plan_create_ragged(p32(bf), p32(flat), n, C.byref(h)) == 0
+    kind, idx, ubf = _launch_plan(stub, h, n)
+    assert kind == 2 and idx is None and ubf == 40
+    assert stub.afsk_group_plan_destroy(h) == 0
+    # ---- several rates + ragged lengths: rate buckets inside windows (largest bucket first), each by length
+    rates = np.array([40, 160, 20, 300, 128], np.int32)
+    bf = rates[rng.integers(0, 5, n)]
+    assert stub.afsk_group_plan_create_ragged(p32(bf), p32(ln), n, C.byref(h)) == 0
+    kind, idx, _ = _launch_plan(stub, h, n)
+    assert kind == 1 and idx is not None and sorted(idx.tolist()) == list(range(n))
+    order = [b for b, _ in sorted(((int(b), int((bf == b).sum())) for b in rates), key=lambda t: -t[1])]
+    for w0 in range(0, n, 4096):
+        w = idx[w0: w0 + 4096]
+        at = 0
+        for b in order:
+            members = w0 + np.nonzero(bf[w0: w0 + 4096] == b)[0]
+            want = members[np.argsort(-ln[members].astype(np.int64), kind="stable")]
+            assert np.array_equal(w[at: at + members.size], want), (w0, b)
+            at += members.size
+    assert stub.afsk_group_plan_destroy(h) == 0
+    # ---- two rates + ragged lengths: below the four-rate rule a walk exists only because of the lengths
+    bf2 = np.where(np.arange(n) % 2 == 0, 40, 160).astype(np.int32)
+    assert stub.afsk_group_plan_create_ragged(p32(bf2), p32(ln), n, C.byref(h)) == 0
+    kind, idx, _ = _launch_plan(stub, h, n)
+    assert kind == 1 and idx is not None
+    assert stub.afsk_group_plan_destroy(h) == 0
+    assert stub.afsk_group_plan_create_ragged(p32(bf2), None, n, C.byref(h)) == 0       # no lengths: stream order (r5)
+    kind, idx, _ = _launch_plan(stub, h, n)
+    assert kind == 1 and idx is None
+    assert stub.afsk_group_plan_destroy(h) == 0
+    # ---- the host entries order ragged one-rate batches by themselves
+    m = 64
+    lens = rng.integers(4096, 40000, m).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+    flat_x = np.zeros(int(lens.sum()), np.int16)
+    outs = [np.zeros(m, np.int32) for _ in range(5)]
+    ob = np.zeros((m, 16), np.uint8)
+    assert stub.afsk_demod_batch_host(flat_x.ctypes.data_as(C.POINTER(C.c_int16)), flat_x.size, p64(offs), p32(lens),
+                                      p32(np.full(m, 40, np.int32)), 14000, m, ob.ctypes.data_as(C.POINTER(C.c_uint8)), 16,
+                                      *(p32(a) for a in outs)) == 0
+    kind, idx, ubf = _walk(stub, m)
+    assert kind == 2 and ubf == 40 and np.array_equal(idx, np.argsort(-lens.astype(np.int64), kind="stable"))
+    assert stub.afsk_host_scratch_release() == 0
+
+
 def test_egress_writes_what_the_stdlib_writer_writes(stub, tmp_path):
     """afsk_wav_egress: every file byte for byte what `wave` writes for 1 channel / 16 bit / 48000 Hz
     (SoundOutput.writeToFile, afskmodem.py:256-263) -- streams smaller and larger than a staging window, empty

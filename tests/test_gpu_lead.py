@@ -132,3 +132,72 @@ def test_uniform_kernels_with_random_lead_ins_small_and_large(torch_cuda):
         check(torch, b, res, min(n, 512), f"{baud} baud x {n}")
         del b, res
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ ragged batches (r6: length-aware plans)
+def ragged_batch(torch, n, bauds, seed, lo=12000, hi=192000):
+    """n streams back to back, lengths log-uniform in [lo, hi] samples (0.25 ... 4 s), each a whole Transmitter frame
+    (training 0.1 s) with as many payload bytes as fit."""
+    dev = "cuda:0"
+    rng = np.random.default_rng(seed)
+    baud = np.asarray([bauds[i % len(bauds)] for i in range(n)], np.int32)
+    bf = (48000 // baud).astype(np.int32)
+    ln = np.exp(rng.uniform(np.log(lo), np.log(hi), n)).astype(np.int32) & ~np.int32(7)
+    ts = np.array([synth.ts_cycles_for(int(b), 0.1) for b in baud], np.int32)
+    plen = np.maximum(0, (ln.astype(np.int64) - ts.astype(np.int64) * 2 * bf - 4 * bf - 4800) // (14 * bf.astype(np.int64))).astype(np.int32)
+    payload = synth.payload_bytes(seed, 0, n, max(1, int(plen.max())))
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x = torch.empty(int(ln.astype(np.int64).sum()), dtype=torch.int16, device=dev)
+    d_off, d_ln, d_bf = t(off), t(ln), t(bf)
+    batch.modulate_batch(t(payload), t(plen), d_bf, t(ts), d_off, d_ln, int(ln.max()), x, True)
+    torch.cuda.synchronize()
+    return dict(x=x, off=d_off, ln=d_ln, bf=d_bf, h_off=off, h_ln=ln, h_bf=bf, payload=payload, plen=plen)
+
+
+def same_results(a, b, tag):
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), (tag, f)
+    m = np.arange(a.bytes.shape[1])[None, :] < a.nbytes[:, None]
+    assert not ((a.bytes != b.bytes) & m).any(), (tag, "bytes")
+
+
+def test_ragged_lengths_longest_first_walk_changes_nothing_but_the_order(torch_cuda):
+    """A ragged one-rate batch through the plain uniform launch (stream order), through a length-aware plan (the uniform
+    kernel walking the longest-first list) and through demod_batch(stream_len_host=): identical outputs at the original
+    stream numbers, equal to the payloads and -- on a sample -- to the CPU oracle.  Then four rates."""
+    torch = torch_cuda
+    n = 12288
+    b = ragged_batch(torch, n, (1200,), seed=6200)
+    stride = batch.out_stride_for(int(b["h_ln"].max()), 40)
+    plain = batch.demod_batch(b["x"], b["off"], b["ln"], 40, 14000, out_stride=stride, entry="uniform")
+    plan = batch.GroupPlan(b["h_bf"], "cuda:0", stream_len=b["h_ln"])
+    assert plan.groups() == [(40, n)]
+    walked = batch.demod_batch(b["x"], b["off"], b["ln"], None, 14000, out_stride=stride, plan=plan)
+    auto = batch.demod_batch(b["x"], b["off"], b["ln"], 40, 14000, out_stride=stride, stream_len_host=b["h_ln"])
+    torch.cuda.synchronize()
+    p, w, a = plain.cpu(), walked.cpu(), auto.cpu()
+    same_results(p, w, "plan vs stream order")
+    same_results(p, a, "stream_len_host vs stream order")
+    pays = w.payloads()
+    assert all(pays[s] == b["payload"][s, : b["plen"][s]].tobytes() for s in range(n))
+    idx = np.linspace(0, n - 1, 768).astype(np.int64)
+    xs = b["x"].cpu().numpy()
+    pieces = [xs[b["h_off"][i]: b["h_off"][i] + b["h_ln"][i]] for i in idx]
+    ln = np.array([len(q) for q in pieces], np.int32)
+    off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+    want = O.demod_batch(np.concatenate(pieces), off, ln, b["h_bf"][idx], 14000, out_stride=stride, n_threads=16)
+    for f in FIELDS:
+        assert np.array_equal(getattr(w, f)[idx], want[f]), f
+    del plain, walked, auto, plan, b
+    # ---- four rates (the per-stream kernel walking rate buckets, each longest first) against stream order
+    b = ragged_batch(torch, 8192, (1200, 300, 2400, 800), seed=6201)
+    stride = batch.out_stride_for(int(b["h_ln"].max()), int(b["h_bf"].min()))
+    mixed = batch.demod_batch(b["x"], b["off"], b["ln"], b["bf"], 14000, out_stride=stride, entry="mixed")
+    walked = batch.demod_batch(b["x"], b["off"], b["ln"], b["h_bf"], 14000, out_stride=stride, stream_len_host=b["h_ln"])
+    torch.cuda.synchronize()
+    same_results(mixed.cpu(), walked.cpu(), "four rates, ragged")
+    pays = walked.cpu().payloads()
+    assert all(pays[s] == b["payload"][s, : b["plen"][s]].tobytes() for s in range(8192))
+    del mixed, walked, b
+    torch.cuda.empty_cache()

@@ -412,7 +412,8 @@ def test_bench_default_line_at_n1_is_compact_and_complete():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["match_rate"] == 1.0 and d["roundtrip_match_rate"] == 1.0
     subs = d["sub_records"]
-    assert {"config2", "config3", "config4", "config5_lead", "f1_modulate", "f2_gate", "f3_wav_ingest", "rates_65536"} == set(subs)
+    assert {"config2", "config3", "config4", "config5_lead", "f1_modulate", "f2_gate", "f2_chain", "f3_wav_ingest", "rates_65536"} == set(subs)
+    assert subs["f2_chain"]["roundtrip"] == 1.0 and subs["f2_chain"]["match_rate"] == 1.0 and subs["f2_chain"]["chain_ms"] > 0
     for name in ("config2", "config3", "config4", "config5_lead", "f1_modulate", "f3_wav_ingest"):
         assert subs[name]["match_rate"] == 1.0, name
     # r6: the lead-in workload (arbitrary clock index: 7 of 8 streams off the 16-byte grid) decodes and is reported

@@ -332,3 +332,148 @@ def measure_rates(ctx: Ctx, steps: int = 120, n_streams: int = 4096, check_strea
     if not ctx.args.no_cpu_baseline:
         doc["min_match_rate"] = min(r["match_rate"] for r in rows.values())
     return doc
+
+
+def measure_gate_chain(ctx: Ctx, reps: int = 20, n_captures: int = 65536, max_bursts: int = 1, check_streams: int = 1024) -> dict:
+    """f2 -> demod END TO END (r6): 65536 one-second captures whose burst starts anywhere inside the first 2048-frame
+    block (the config5_lead shard: lead-in noise, then a Transmitter frame) -> afsk_gate_batch (Receiver.__listen,
+    ref:299-319) -> GateResult.burst_slots (fixed slots, no host round trip) -> afsk_demod_batch_uniform on the bursts
+    (what Receiver.receive would hand to __decodeBits, ref:402-417) -> decoded bytes, as ONE captured HIP graph.
+    A burst the gate cuts at a block boundary starts in the middle of the training sequence: its clock index is
+    arbitrary.  Algorithmic bytes: the gate reads every whole block of every capture, the demodulator the burst up to
+    its squelch symbol (both algorithms need the samples: counted once each)."""
+    from afskmodem_amd import batch
+    torch = ctx.torch
+    sh = Shard(ctx, "config5_lead", n_captures)
+    n = sh.n_local
+    x = sh.inputs[0]
+    stride = batch.out_stride_for(STREAM_LEN, 40)
+    out = batch.alloc_result(n * max_bursts, stride, ctx.dev)
+    keep = {}
+
+    def chain():
+        g = batch.gate_batch(x, sh.off, sh.ln, STREAM_LEN, 18000, 14000, max_bursts, stream=ctx.cur)
+        s_off, s_len = g.burst_slots(sh.off)
+        batch.demod_batch(x, s_off, s_len, 40, 14000, out=out, stream=ctx.cur)
+        keep["g"], keep["slots"] = g, (s_off, s_len)
+        return g
+
+    with torch.cuda.stream(ctx.cur):
+        chain()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=ctx.dev)
+    side.wait_stream(ctx.cur)
+    saved_cur = ctx.cur
+    try:
+        ctx.cur = side
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                chain()
+    finally:
+        ctx.cur = saved_cur
+    torch.cuda.synchronize()
+    out.flat.zero_()
+    with torch.cuda.stream(ctx.cur):
+        avg, med, _ = event_timed(torch, ctx.cur, graph.replay, reps)
+    # the parts, eagerly, for the split
+    g = keep["g"]
+    s_off, s_len = keep["slots"]
+    with torch.cuda.stream(ctx.cur):
+        g_avg, _, _ = event_timed(torch, ctx.cur, lambda: batch.gate_batch(x, sh.off, sh.ln, STREAM_LEN, 18000, 14000, max_bursts, stream=ctx.cur), reps)
+        d_avg, _, _ = event_timed(torch, ctx.cur, lambda: batch.demod_batch(x, s_off, s_len, 40, 14000, out=out, stream=ctx.cur), reps)
+    res = out.cpu()
+    pays = res.payloads()
+    nb = g.n_bursts.cpu().numpy()
+    ok = sum(pays[s * max_bursts] == sh.payload_h[s, : sh.plen_h[s]].tobytes() for s in range(n))
+    lens = s_len.cpu().numpy().astype(np.int64)
+    active = np.where(res.status == 0, np.minimum(res.term_frame.astype(np.int64) + (res.nbits.astype(np.int64) + 1) * 40, lens), np.minimum(lens, 4096))
+    blocks = STREAM_LEN // 2048
+    alg_gate = 2 * n * blocks * 2048 + 4 * n * blocks + 12 * n
+    alg_demod = int(2 * active.sum()) + int(np.minimum(res.nbytes, stride).sum()) + 20 * n * max_bursts
+    rec = {"row": "f2 -> demod chain as ONE HIP graph: afsk_gate_batch -> burst_slots -> afsk_demod_batch_uniform (config5_lead captures)",
+           "captures": n, "max_bursts": max_bursts, "launches": reps, "unit": "Msamples/s",
+           "value": round(n * STREAM_LEN / (avg * 1e-3) / 1e6, 1),
+           "chain_ms": round(avg, 5), "chain_ms_median": round(med, 5), "gate_ms_alone": round(g_avg, 5), "demod_ms_alone": round(d_avg, 5),
+           "bursts_found": int(nb.sum()), "roundtrip_match_rate": ok / n,
+           "clock_index_unaligned_share": round(float(((res.clock_idx[res.status == 0].astype(np.int64) * 2) & 15).astype(bool).mean()), 4),
+           "roofline": roofline_obj(alg_gate + alg_demod, avg, med),
+           "demod_frac_alone": round(alg_demod / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "gate_frac_alone": round(alg_gate / (g_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if not ctx.args.no_cpu_baseline:
+        from oracle import afsk_oracle as O   # checker only
+        ns = min(check_streams, n)
+        so, sl = s_off.cpu().numpy()[: ns * max_bursts], s_len.cpu().numpy()[: ns * max_bursts]
+        hx = x[: ns * STREAM_LEN].cpu().numpy()
+        want = O.demod_batch(hx, so, sl, np.full(ns * max_bursts, 40, np.int32), 14000, out_stride=stride, n_threads=usable_cpus())
+        same = all(np.array_equal(getattr(res, f)[: ns * max_bursts], want[f]) for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"))
+        rec["oracle_match_rate"] = 1.0 if same else 0.0
+        rec["oracle_sample_streams"] = ns
+    del graph
+    return rec
+
+
+def measure_ragged(ctx: Ctx, reps: int = 10, seconds: int = 65536, baud: int = 1200) -> dict:
+    """Ragged batches (r6): stream lengths log-uniform in 0.25 ... 4 s, `seconds` seconds of audio in all, one rate --
+    through (a) the plain uniform launch in stream order, (b) a length-aware plan (afsk_group_plan_create_ragged: the
+    uniform kernel walks the streams longest first inside windows of 4096) -- against (c) the same number of samples as
+    1 s streams of the same frame shape (training 0.1 s).  One wavefront decodes one stream whatever its length and a
+    workgroup of four keeps its share of a CU until its longest stream ends."""
+    from afskmodem_amd import batch, synth
+    torch = ctx.torch
+    bf = 48000 // baud
+    rng = np.random.default_rng(4242)
+    lens = []
+    total = 0
+    while total < seconds * STREAM_LEN:
+        l = int(np.exp(rng.uniform(np.log(12000), np.log(192000)))) & ~7
+        lens.append(l)
+        total += l
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.dev)  # noqa: E731
+    ts_c = synth.ts_cycles_for(baud, 0.1)
+
+    def make(ln):
+        n = ln.size
+        plen = np.maximum(0, (ln.astype(np.int64) - ts_c * 2 * bf - 4 * bf - 4800) // (14 * bf)).astype(np.int32)
+        payload = synth.payload_bytes(77, 0, n, max(1, int(plen.max())))
+        off = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]).astype(np.int64)
+        x = torch.empty(int(ln.astype(np.int64).sum()), dtype=torch.int16, device=ctx.dev)
+        d_off, d_ln = t(off), t(ln)
+        batch.modulate_batch(t(payload), t(plen), t(np.full(n, bf, np.int32)), t(np.full(n, ts_c, np.int32)), d_off, d_ln,
+                             int(ln.max()), x, baud != 12000)
+        stride = batch.out_stride_for(int(ln.max()), bf)
+        return dict(x=x, off=d_off, ln=d_ln, n=n, plen=plen, payload=payload, stride=stride, out=batch.alloc_result(n, stride, ctx.dev))
+
+    def run(b, plan, tag):
+        def launch():
+            batch.demod_batch(b["x"], b["off"], b["ln"], None if plan is not None else bf, 14000, out=b["out"],
+                              plan=plan, entry="auto" if plan is not None else "uniform", stream=ctx.cur)
+        b["out"].flat.zero_()
+        with torch.cuda.stream(ctx.cur):
+            avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
+        res = b["out"].cpu()
+        pays = res.payloads()
+        ok = sum(pays[s] == b["payload"][s, : b["plen"][s]].tobytes() for s in range(b["n"])) / b["n"]
+        hl = b["ln"].cpu().numpy().astype(np.int64)
+        active = np.minimum(np.maximum(res.term_frame.astype(np.int64) + (res.nbits.astype(np.int64) + 1) * bf, 4096), hl)
+        alg = int(2 * active.sum()) + int(np.minimum(res.nbytes, b["stride"]).sum()) + 20 * b["n"]
+        return {"what": tag, "streams": b["n"], "kernel_ms": round(avg, 5), "kernel_ms_median": round(med, 5),
+                "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                "roundtrip_match_rate": ok}
+
+    rag = make(np.asarray(lens, np.int32))
+    plan = batch.GroupPlan(np.full(rag["n"], bf, np.int32), ctx.dev, stream_len=np.asarray(lens, np.int32))
+    a = run(rag, None, "ragged, stream order (plain uniform launch)")
+    b_ = run(rag, plan, "ragged, length-aware plan (longest first inside windows of 4096 streams)")
+    a2 = run(rag, None, "ragged, stream order again")
+    del rag, plan
+    uni = make(np.full(total // STREAM_LEN, STREAM_LEN, np.int32))
+    c = run(uni, None, "the same samples as 1 s streams")
+    del uni
+    per_byte = lambda r: r["kernel_ms"] / r["algorithmic_bytes_per_launch"]  # noqa: E731
+    return {"row": f"ragged one-rate batch ({baud} baud, lengths log-uniform 0.25 ... 4 s, {total / 48000:.0f} s of audio) vs the same samples as 1 s streams",
+            "launches": reps, "stream_order": a, "length_aware_plan": b_, "stream_order_again": a2, "uniform_1s": c,
+            "ragged_over_uniform_time_per_byte_stream_order": round(per_byte(a) / per_byte(c), 4),
+            "ragged_over_uniform_time_per_byte_planned": round(per_byte(b_) / per_byte(c), 4),
+            "value": round(total / (b_["kernel_ms"] * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+            "roofline": {"frac": b_["frac"]}, "roundtrip_match_rate": min(a["roundtrip_match_rate"], b_["roundtrip_match_rate"], c["roundtrip_match_rate"])}
