@@ -588,7 +588,7 @@ int wav_probe_fd(int fd, int64_t* data_off, int64_t* data_bytes) {
 // per-stream kernel (every geometry a Receiver can have is compiled into it) that walks the streams BUCKET BY
 // BUCKET through an index list, so that the waves resident on a CU at any time run the same geometry's code
 // (wave w decodes stream index[w]; every per-stream array stays indexed by the stream number).
-// Measured alternatives (profiles/r4_exp2_grouped_modes.txt): one launch of the uniform kernel per bucket --
+// Measured alternatives (profiles/archive/r4_exp2_grouped_modes.txt): one launch of the uniform kernel per bucket --
 // on side streams forked / joined with events, or one after the other -- loses 2 ... 70 % to the cross-queue
 // hand-over (~27 us per step) and to kernels of different queues hardly overlapping on gfx950
 // (hipExtAnyOrderLaunch is not honoured there); the rate-sorted single launch gains 3 ... 12 % over stream
@@ -651,7 +651,10 @@ struct GroupPlan {
             first += count[(size_t)bf];
         }
         h_upload.resize(2 * (size_t)n);
-        const int32_t window = sort_window();
+        // (ragged batches walk windows twice as long: 8192 streams measured best -- time per byte against 1 s streams
+        // 1.06 / 1.03 / 1.00 / 1.01 / 1.02 for windows of 2048 / 4096 / 8192 / 16384 / the whole batch,
+        // profiles/r6_ragged_windows.txt -- the longest streams of a window live several generations of short ones)
+        const int32_t window = by_length && !std::getenv("AFSK_GROUP_WINDOW") ? 2 * sort_window() : sort_window();
         // longest first inside [b, e) of the index list (one bucket of one window)
         auto by_len = [&](size_t b, size_t e) {
             if (by_length && e - b > 1)

@@ -24,12 +24,15 @@
 //             its own run of consecutive sync offsets in registers and slides the SAD with 7
 //             v_dot2c_i32_i16 per offset.  (The first design -- a DPP prefix-sum producer feeding a
 //             circular LDS window, 7 lookups per offset -- was LDS-bandwidth bound and is gone.)
+//   re-base   (r6) once the clock index is known the ring contents and the buffer descriptor move by the whole dwords
+//             of (2*ci) & 15, so that every stream runs one of two forms of its round loop, both with the tail hint
 //   phase B   ref:342-351: every lane owns an 80-byte piece (40 samples: one
 //             1200-baud symbol, two 2400-baud symbols, half a 600-baud or a quarter of a
-//             300-baud symbol) at ring byte (2*ci + 5120*r + 80*lane) mod 16 KiB, read as five
-//             aligned ds_read_b128, or six re-aligned in registers by the wave-uniform shift
-//             (2*ci) & 15 (v_alignbyte).  After the reads of round r the five chunks
-//             it consumed are refilled immediately (11 KiB stay in flight).
+//             300-baud symbol) at ring byte (byte0 + 5120*r + 80*lane) mod 16 KiB, byte0 = the ring byte of
+//             symbol 0 after the stream has been re-based on the clock index (FastRing::rebase, r6: a multiple
+//             of 16, or 2 bytes past one for an odd clock index): five aligned ds_read_b128, or -- the ODD form --
+//             six, shifted down by one sample in registers (v_alignbyte).  After the reads of round r the five
+//             chunks it consumed are refilled immediately (11 KiB stay in flight).
 //   phase C   ref:361-378, 145-163, 393-399: terminator scan and squelch stop on wave-uniform
 //             ballot masks; the Hamming decode + byte pack is deferred and vectorised.
 //

@@ -45,7 +45,7 @@ constexpr int kHintMinStreamsGrouped = 4096;   // the same kernel walking a rate
                                                // +1.3 % at 4096 was measured in stream order (r5)
 // uniform kernels of bit_frames 4 / 8 (large-launch form, hint and warming alike): 12000 baud gains from 8192
 // streams on (0.65 -> 0.68; 16384: 0.65 -> 0.71; 32768: 0.72 -> 0.77), 6000 baud loses 2 % at 8192 / 12288 and gains
-// from 16384 on (0.69 -> 0.71; 32768: 0.69 -> 0.76) -- profiles/r4_exp4_hint_short.txt
+// from 16384 on (0.69 -> 0.71; 32768: 0.69 -> 0.76) -- profiles/archive/r4_exp4_hint_short.txt
 constexpr int kHintMinStreamsShort4 = 8192;
 constexpr int kHintMinStreamsShort8 = 16384;
 constexpr int kHintMinStreamsUniform = 4096;   // uniform kernels (no scalar-register pressure): -0.8 ... -1.6 % at 4096 streams and 1.02 x

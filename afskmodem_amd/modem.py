@@ -18,6 +18,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 import wave
 from datetime import datetime
@@ -525,7 +526,11 @@ class Transmitter:
         the GPU with the wav writer's decimate / duplicate quirk (``afsk_modulate_batch``; ref:452-469, 239-244)
         and written out by ``afsk_wav_egress`` -- every file byte for byte what ``save`` writes.  A baud rate the
         device modulator has no symbol geometry for (``48000 / baud`` not a multiple of 4: the reference still
-        modulates it, the Receiver rejects it) takes the host path per file."""
+        modulates it, the Receiver rejects it) takes the host path per file.
+
+        Error behaviour against a loop of ``save`` calls: a file the batch cannot write is removed and written again
+        through ``save`` itself, which raises what the reference raises for it -- but by then the batch HAS written the
+        files behind it in the list, where the reference's sequential loop would have stopped at the failing one."""
         from . import batch
         payloads = [d.encode("utf-8") if isinstance(d, str) else bytes(d) for d in data_list]      # ref:482-483
         names = list(filenames)
@@ -561,7 +566,14 @@ class Transmitter:
         status = batch.save_wav_batch(samples, offs, lens, names)
         for i in np.nonzero(status != 0)[0]:
             # every file the egress could not write goes through the reference's own per-file path: it is written
-            # after all (a transient open / write failure), or raises what the stdlib writer raises for that file
+            # after all (a transient open / write failure), or raises what the stdlib writer raises for that file.
+            # What the egress may have left of it goes first (a partly written file must not survive a failed save).
+            # One difference from a loop of ``save`` calls remains and is documented in ``save_batch``: the batch has
+            # already written the files BEHIND a failing one, where the reference's loop would have stopped at it.
+            try:
+                os.unlink(names[int(i)])
+            except OSError:
+                pass
             self.save(payloads[int(i)], names[int(i)])
 
     def wav_samples(self, data: str | bytes, total: int | None = None) -> np.ndarray:

@@ -164,13 +164,50 @@ def test_rank_watchdog_sigterm_while_the_main_thread_is_stuck(tmp_path):
 def test_failure_line_stays_under_the_cap():
     import bench
     hbs = {str(r): {"phase": "x" * 120, "age_s": 1.0, "since_start_s": 2.0, "alive": True} for r in range(8)}
-    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r4_bench_full_n1.json")))
     partial = bench.compact_line(full, "gpurun_out/bench_full_n1.json")
     line = bench.failure_line(8, 20, 5, "e" * 2000, "p" * 500, hbs, partial)
     assert len(json.dumps(line)) < bench.LINE_CAP and line["value"] == full["value"] and line["incomplete"] is True
     line = bench.failure_line(8, 20, 5, "boom", "pg up", hbs, None)
     assert len(json.dumps(line)) < bench.LINE_CAP and line["value"] is None
     assert set(CONTRACT_KEYS) <= set(line)
+
+
+def test_omp_num_threads_is_parsed_like_openmp_does():
+    """A legal list-form or empty OMP_NUM_THREADS must not kill the launcher before any rank has started (r5 advisor)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_launch
+    assert bench_launch.omp_threads("8,2", 4) == 8 and bench_launch.omp_threads(" 6 , 2", 4) == 6
+    assert bench_launch.omp_threads("", 4) == 4 and bench_launch.omp_threads(None, 4) == 4
+    assert bench_launch.omp_threads("auto", 4) == 4 and bench_launch.omp_threads("0", 4) == 4 and bench_launch.omp_threads(3, 4) == 3
+    # and the launcher as a whole: stub ranks, a list-form value in the environment -> the line is relayed, exit 0
+    old = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "8,2"
+    try:
+        rc, out = _launch("ok")
+    finally:
+        if old is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = old
+    assert rc == 0 and _one_line(out)["ranks_seen"] == 2
+
+
+def test_only_node_zero_prints_under_a_multi_node_external_launcher(tmp_path):
+    """bench.py measures one node; if someone launches it across nodes the heartbeat directory is per node, and the
+    lowest rank of every node would win its own claim file: ranks with GROUP_RANK != 0 never print (r5 advisor)."""
+    code = (
+        "import os, sys, time, types\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "hb = bench.Heartbeat(int(os.environ['RANK']), 4)\n"
+        "dog = bench.Watchdog(hb, types.SimpleNamespace(steps=5, warmup=1), 2.0)\n"
+        "time.sleep(600)\n")
+    env = dict(os.environ, WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998", AFSK_BENCH_HB_DIR=str(tmp_path),
+               RANK="2", GROUP_RANK="1")
+    env.pop("AFSK_BENCH_LAUNCHER", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert p.returncode == bench_mod().EXIT_DEADLINE and p.stdout.strip() == ""
 
 
 def test_thread_budget_is_divided_by_the_local_world(monkeypatch):
@@ -276,7 +313,7 @@ def test_stub_rank_line_names_the_headline_workload():
     assert doc["config"]["workload"] == bench.config_block(bench.plan(1)["main"], 65536, 1)["workload"]
 
 
-@pytest.mark.parametrize("record", ["r3_bench_n1.json", "r3_bench_n8_diagnostic_gloo_shared_gpu.json",
+@pytest.mark.parametrize("record", ["archive/r3_bench_n1.json", "archive/r3_bench_n8_diagnostic_gloo_shared_gpu.json",
                                     "archive/r2_bench_n1.json"])
 def test_result_line_is_compact_and_complete(record):
     """The contract that broke in round 3 (a 26 KB line, of which the driver kept the last 8 KB): whatever the full
@@ -305,7 +342,7 @@ def test_result_line_is_compact_and_complete(record):
 def test_result_line_survives_a_bloated_record():
     """Riders that do not exist yet cannot push the line over the cap: the summaries go, the contract stays."""
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r3_bench_n1.json")))
     full["sub_records"].update({f"future_{i}": {"value": i, "roofline": {"frac": 0.5}, "match_rate": 1.0,
                                                 "entry": "e" * 40} for i in range(200)})
     line = bench.compact_line(full, None)
@@ -317,7 +354,7 @@ def test_result_line_survives_a_bloated_record():
 def test_full_record_goes_to_a_file_not_to_the_streams(tmp_path, monkeypatch, capsys):
     import bench
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r3_bench_n1.json")))
     path = bench.write_full_record(full, 1)
     assert path == os.path.join("gpurun_out", "bench_full_n1.json")
     assert json.load(open(tmp_path / path)) == full
@@ -341,7 +378,7 @@ def test_cpu_baseline_calibration_is_a_tracked_artefact():
     assert cal["file"] == "profiles/cpu_reference_calibration.json"
     assert cal["pyref_over_reference"] == cj["pyref_over_reference_1200"]
     # and it survives the compaction of the result line
-    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r3_bench_n1.json")))
     full["cpu_baseline"]["calibration"] = cal
     assert bench.compact_line(full, None)["cpu_baseline"]["calibration"] == cal
 
@@ -360,7 +397,7 @@ def test_rider_rows_live_outside_bench_py_and_import_on_cpu():
     assert "import bench_rows" in src and src.count("def rider(") == 1
     assert len(src.splitlines()) < 1400
     # a failed rider's summary is its error, nothing else -- and the line stays parseable
-    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r4_bench_full_n1.json")))
     full["sub_records"]["f3_wav_ingest"] = {"error": "OSError: [Errno 2] No such file or directory: '/proc/afsk_no_such_dir'"}
     line = bench.compact_line(full, None)
     assert line["sub_records"]["f3_wav_ingest"] == {"error": full["sub_records"]["f3_wav_ingest"]["error"][:120]}

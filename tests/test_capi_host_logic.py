@@ -270,11 +270,12 @@ def _launch_plan(stub, h, n):
 
 
 def test_group_plan_takes_the_longest_streams_first_when_lengths_are_ragged(stub):
-    """afsk_group_plan_create_ragged (r6): inside every window of 4096 streams and every rate bucket the walk is by
-    descending length (stable), for one rate too (the uniform kernel then walks the list); equal lengths -- or no
-    lengths -- leave the r5 plan byte for byte."""
+    """afsk_group_plan_create_ragged (r6): inside every window of 8192 streams (ragged plans: twice the window of a
+    rate-only plan) and every rate bucket the walk is by descending length (stable), for one rate too (the uniform
+    kernel then walks the list); equal lengths -- or no lengths -- leave the r5 plan byte for byte."""
     rng = np.random.default_rng(8)
-    n = 10000
+    n = 20000
+    W = 8192
     # ---- one rate, ragged lengths: uniform kernel + index list, windows of 4096, longest first, stable
     bf = np.full(n, 40, np.int32)
     ln = rng.integers(12000, 192001, n).astype(np.int32)
@@ -284,10 +285,10 @@ def test_group_plan_takes_the_longest_streams_first_when_lengths_are_ragged(stub
     kind, idx, ubf = _launch_plan(stub, h, n)
     assert kind == 2 and ubf == 40 and idx is not None
     assert sorted(idx.tolist()) == list(range(n))                           # a permutation
-    for w0 in range(0, n, 4096):
-        w = idx[w0: w0 + 4096]
-        assert w.min() == w0 and w.max() == min(n, w0 + 4096) - 1          # a window holds its own streams
-        want = w0 + np.argsort(-ln[w0: w0 + 4096].astype(np.int64), kind="stable")
+    for w0 in range(0, n, W):
+        w = idx[w0: w0 + W]
+        assert w.min() == w0 and w.max() == min(n, w0 + W) - 1             # a window holds its own streams
+        want = w0 + np.argsort(-ln[w0: w0 + W].astype(np.int64), kind="stable")
         assert np.array_equal(w, want)
     assert stub.afsk_group_plan_destroy(h) == 0
     # ---- the same rates and lengths that do NOT differ enough: plain uniform launch, no list
@@ -303,11 +304,11 @@ def test_group_plan_takes_the_longest_streams_first_when_lengths_are_ragged(stub
     kind, idx, _ = _launch_plan(stub, h, n)
     assert kind == 1 and idx is not None and sorted(idx.tolist()) == list(range(n))
     order = [b for b, _ in sorted(((int(b), int((bf == b).sum())) for b in rates), key=lambda t: -t[1])]
-    for w0 in range(0, n, 4096):
-        w = idx[w0: w0 + 4096]
+    for w0 in range(0, n, W):
+        w = idx[w0: w0 + W]
         at = 0
         for b in order:
-            members = w0 + np.nonzero(bf[w0: w0 + 4096] == b)[0]
+            members = w0 + np.nonzero(bf[w0: w0 + W] == b)[0]
             want = members[np.argsort(-ln[members].astype(np.int64), kind="stable")]
             assert np.array_equal(w[at: at + members.size], want), (w0, b)
             at += members.size

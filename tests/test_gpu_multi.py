@@ -353,7 +353,7 @@ def test_bench_three_rank_rehearsal_full_size_on_one_gpu():
     ranks on one device; throughput is meaningless by construction.  Three ranks, not eight: the GPU boxes
     allow 6 processes per device, and this test runner and the launching bench.py process are two of
     them; the 8-rank line recorded before that limit existed is
-    profiles/r3_bench_n8_diagnostic_gloo_shared_gpu.json.)"""
+    profiles/archive/r3_bench_n8_diagnostic_gloo_shared_gpu.json.)"""
     import json
     import subprocess
     import sys

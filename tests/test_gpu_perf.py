@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from afskmodem_amd import _native, batch, synth
-from tests.test_gpu_parity import synth_batch
+from tests.gpu_common import synth_batch
 
 pytestmark = [pytest.mark.perf,
               pytest.mark.skipif(_native.device_count() == 0, reason="needs an MI355X")]

@@ -532,8 +532,9 @@ def test_plan_cache_is_thread_safe_and_never_closes_a_plan_in_use(monkeypatch):
     closed, live = [], []
 
     class FakePlan:
-        def __init__(self, bit_frames, device=None):
+        def __init__(self, bit_frames, device=None, stream_len=None):
             self.bit_frames = np.ascontiguousarray(np.asarray(bit_frames, np.int32).reshape(-1))
+            self.stream_len = stream_len
             self.closed = False
             live.append(self)
 
@@ -564,3 +565,12 @@ def test_plan_cache_is_thread_safe_and_never_closes_a_plan_in_use(monkeypatch):
         th.join()
     assert not errors, errors[:3]
     assert len(batch._PLAN_CACHE) <= batch._PLAN_CACHE_MAX and not closed      # the cache itself never closes a plan
+    # r6: ragged host-side lengths are part of a plan's identity, lengths that do not differ enough are not
+    arr = np.full(16, 40, np.int32)
+    flat, ragged = np.full(16, 48000, np.int32), np.arange(16, dtype=np.int32) * 9000 + 12000
+    assert batch.lengths_ragged(ragged) and not batch.lengths_ragged(flat) and not batch.lengths_ragged(ragged[:4])
+    p0 = batch._cached_plan(arr, 16, "cuda:0")
+    assert batch._cached_plan(arr, 16, "cuda:0", flat) is p0 and p0.stream_len is None
+    p1 = batch._cached_plan(arr, 16, "cuda:0", ragged)
+    assert p1 is not p0 and np.array_equal(p1.stream_len, ragged) and batch._cached_plan(arr, 16, "cuda:0", ragged) is p1
+    assert batch._cached_plan(arr, 16, "cuda:0", ragged[::-1].copy()) is not p1

@@ -1,7 +1,7 @@
 """CPU checks (numpy, exhaustive where feasible) of the arithmetic identities the HIP kernels
 rely on.  They restate the tricks, not the kernels: each test names the place in
 afskmodem_amd/csrc that uses the identity, so a reader can see why the integer shortcuts are
-exact.  The kernels themselves are checked against the oracle in tests/test_gpu_parity.py."""
+exact.  The kernels themselves are checked against the oracle in tests/test_gpu_*.py."""
 import numpy as np
 import pytest
 

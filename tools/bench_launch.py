@@ -109,6 +109,17 @@ HB_MAX_AGE_S = 1800.0        # heartbeat files older than this belong to an earl
 EXIT_RANK_FAILED, EXIT_DEADLINE, EXIT_NO_LINE = 3, 4, 1
 
 
+def omp_threads(value, default: int) -> int:
+    """OMP_NUM_THREADS as OpenMP reads it -- a comma list gives one count per nesting level ("8,2"): the first -- or
+    `default` when it is unset, empty or not a positive number.  (The launcher must not die of a legal value before any
+    rank has started: there would be no diagnostic line.)"""
+    try:
+        n = int(str(value).split(",")[0].strip())
+        return n if n > 0 else default
+    except (TypeError, ValueError):
+        return default
+
+
 def hb_dir_for_env(env=None) -> str:
     """The heartbeat directory of this job: AFSK_BENCH_HB_DIR (set by the launcher), else one derived from the
     rendezvous port, so that the ranks of an external torchrun agree on it without talking to each other."""
@@ -265,7 +276,7 @@ def self_launch(n: int, argv: list[str], script: str | None = None, deadline_s: 
     # host threads: the box's usable CPUs are shared by the N ranks (OpenMP, the I/O pool of libafsk_amd.so and
     # the CPU-oracle legs all size themselves from these)
     share = max(1, usable_cpus(local_world=1) // n)
-    env["OMP_NUM_THREADS"] = str(min(int(env.get("OMP_NUM_THREADS", share)), share))
+    env["OMP_NUM_THREADS"] = str(min(omp_threads(env.get("OMP_NUM_THREADS"), share), share))
     env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
                 "MASTER_PORT": str(free_port()), "AFSK_BENCH_HB_DIR": hb_dir, "AFSK_BENCH_LAUNCHER": "1",
                 "AFSK_BENCH_DEADLINE_S": str(deadline_s)})
@@ -415,6 +426,11 @@ class Watchdog:
 
     def _maybe_print(self, rc: int, why: str, where: str) -> None:
         hb = self.hb
+        # bench.py measures ONE node (the contract's `--gpus N`): under an external multi-node torchrun the heartbeat
+        # directory is per node, so only node 0's ranks may print -- otherwise every node's lowest rank would win its own
+        # claim file and the job would print one failure line per node
+        if os.environ.get("GROUP_RANK", "0") not in ("", "0"):
+            return
         claim = os.path.join(hb.dir, "line_printed.claim")
         if hb.rank != 0:
             # rank 0 prints if it can; the others step in, lowest rank first, only if nobody has

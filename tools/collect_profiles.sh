@@ -4,8 +4,8 @@
 # line printed under the profiler; the plain bench line of the visit; traffic_latest.json.
 #   bash tools/collect_profiles.sh <tag> [workload ...]
 cd "$(dirname "$0")/.."
-T=${1:-r3}; shift || true
-WL=${*:-config5 config2 config3 custom100 custom150 custom200}
+T=${1:-r6}; shift || true
+WL=${*:-config5 config5_lead config2 config3}
 for w in $WL; do
   # ONE rocprofv3 run per summary: the committed CSV is the very file the summary was computed from (its
   # `kernel_stats_file`; gpurun_out/ accumulates the directories of earlier visits, so never "the first CSV

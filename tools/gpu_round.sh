@@ -3,10 +3,13 @@
 # + f1/f2/f3), and with "prof" rocprofv3 kernel trace + PMC passes (FETCH_SIZE and WRITE_SIZE in
 # separate runs) for the workloads listed in PROF_WL.  Outputs under gpurun_out/.
 #   [SKIP_TESTS=1] [PROF_WL="config5 config2 custom375,160"] bash tools/gpu_round.sh [prof] [tag]
+# With "prof" the LAST action is the check that gpurun_out/traffic_latest.json -- what bench.py reports as
+# roofline.traffic -- was measured on the kernel sources of this tree (tests/test_evidence_current.py checks the
+# committed copy on the CPU): run this as the last GPU visit of a round, then tools/collect_profiles.sh <tag>.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export PROF_TAG=${2:-r3}
+export PROF_TAG=${2:-r6}
 T=$PROF_TAG
 if [ -z "${SKIP_TESTS:-}" ]; then
 ( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/${T}_pytest_gpu.log
@@ -18,10 +21,10 @@ cut -c1-600 gpurun_out/${T}_bench_main.json
 fi
 if [ "${1:-}" = "prof" ]; then
   R=$(pwd)
-  for w in ${PROF_WL:-config5 config2 config3}; do
+  for w in ${PROF_WL:-config5 config5_lead config2 config3}; do
     steps=200; wl="--workload $w"; kern=demod
     case $w in
-      config5|config3|config4) steps=20 ;;
+      config5|config3|config4|config5_lead) steps=20 ;;
       custom*) wl="--workload custom --bauds ${w#custom} --streams ${PROF_STREAMS:-65536}"; steps=20 ;;
     esac
     rm -rf gpurun_out/prof_trace_$w gpurun_out/prof_pmc1_$w gpurun_out/prof_pmc2_$w
@@ -41,4 +44,16 @@ if [ "${1:-}" = "prof" ]; then
   python tools/summarize_prof.py gpurun_out $w 20 --kernel modulate_kernel --name modulate 2>&1 | tail -30
   python tools/summarize_prof.py gpurun_out $w 20 --kernel block_amp_kernel --name gate 2>&1 | tail -30
   python tools/summarize_prof.py gpurun_out $w 20 --kernel gate_scan_kernel --name gate_scan 2>&1 | tail -12
+  # ---- last: the traffic file of this visit belongs to the kernel sources of this tree, and covers the headline
+  python - <<'PY' || { echo "gpu_round.sh: gpurun_out/traffic_latest.json is NOT current -- do not commit it" >&2; exit 1; }
+import json, sys
+sys.path.insert(0, ".")
+import bench
+tj = json.load(open("gpurun_out/traffic_latest.json"))
+h = bench.kernel_source_hash()
+assert tj["kernel_source_hash"] == h, (tj["kernel_source_hash"], h)
+for w in ("config5", "config5_lead", "config2", "config3"):
+    assert w in tj["entries"], w
+print("traffic_latest.json: kernel source", h, {k: v["hbm_bytes_per_launch"] for k, v in tj["entries"].items()})
+PY
 fi
