@@ -103,6 +103,7 @@ MALL_BYTES = 256 << 20  # Infinity Cache: inputs smaller than a few of these are
 METRIC = "Msamples/s demodulated (batched 48 kHz streams) + decoded-byte match rate vs CPU ref"
 PAYLOAD_SEED = 2024
 RATE_ORDER = "cycle"            # --rate-order: how --bauds are laid over the streams of a custom workload
+TRAINING_TIME = 0.5             # --training-time (custom workloads): the Transmitter's training_time (ref:437-438), default 0.5 s
 
 
 def kernel_source_hash() -> str:
@@ -326,10 +327,10 @@ class Shard:
         else:
             baud_arr = np.asarray([bauds[i % len(bauds)] for i in gidx], np.int32)
         bf_h = (48000 // baud_arr).astype(np.int32)
-        plen_h = np.asarray([synth.one_second_payload(int(b)) for b in baud_arr], np.int32)
-        pstride = max(synth.one_second_payload(int(b)) for b in bauds)
+        plen_h = np.asarray([synth.one_second_payload(int(b), TRAINING_TIME) for b in baud_arr], np.int32)
+        pstride = max(synth.one_second_payload(int(b), TRAINING_TIME) for b in bauds)
         payload_h = synth.payload_bytes(PAYLOAD_SEED, first, n, pstride)
-        ts_h = np.asarray([synth.ts_cycles_for(int(b)) for b in baud_arr], np.int32)
+        ts_h = np.asarray([synth.ts_cycles_for(int(b), TRAINING_TIME) for b in baud_arr], np.int32)
         return bf_h, plen_h, payload_h, ts_h
 
     @staticmethod
@@ -1231,6 +1232,9 @@ def main() -> None:
                     help="streams per sub-record (and per SNR of the BER curve) decoded by the CPU oracle")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--bauds", default="", help="with --workload custom: comma list of baud rates cycled over the streams")
+    ap.add_argument("--training-time", type=float, default=0.5,
+                    help="with --workload custom: the Transmitter's training_time in seconds (default 0.5, the reference's): "
+                         "a shorter training sequence leaves more of the second to data symbols (more decoded bytes per stream)")
     ap.add_argument("--lead", default="", help="with --workload custom: lead-in before every frame -- N (samples, the same for every "
                     "stream) or 'random' (per stream 0 ... 2047, like config5_lead): low-level noise, arbitrary clock index")
     ap.add_argument("--rate-order", default="cycle", choices=["cycle", "blocks"],
@@ -1263,11 +1267,17 @@ def main() -> None:
 
     # dmabuf IPC for RCCL on this pool (exported on the boxes already; set before anything initialises HIP)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    global RATE_ORDER
+    global RATE_ORDER, TRAINING_TIME
     RATE_ORDER = args.rate_order
     if args.bauds:
         bl = tuple(int(b) for b in args.bauds.split(","))
         WORKLOADS["custom"] = (WORKLOADS["custom"][0], bl, None, f"custom: streams x 1 s, clean, bauds {list(bl)}, per GPU")
+    if args.training_time != 0.5:
+        if args.workload != "custom":
+            raise SystemExit("--training-time goes with --workload custom (the BASELINE configs use the reference's default)")
+        TRAINING_TIME = args.training_time
+        d = WORKLOADS["custom"]
+        WORKLOADS["custom"] = (d[0], d[1], d[2], d[3] + f", training_time {args.training_time:g} s")
     if args.lead:
         if args.lead == "random":
             LEADS["custom"] = 2048

@@ -9,17 +9,20 @@ OUT=$1; shift
 W=$(mktemp -d); trap 'rm -rf "$W"' EXIT
 cat > "$W/stubs.hip" <<S
 #include "$ROOT/afskmodem_amd/csrc/afsk_kernels.h"
+#include <mutex>
 namespace afsk {
 hipError_t launch_gate(const GateArgs&, hipStream_t) { return hipSuccess; }
 // the demod launchers remember what they were asked to launch ("device" memory is host memory here): the test reads
 // the walk order of a plan back through afsk_stub_last_launch
 static DemodArgs g_last; static int g_last_kind = 0;        // 1 = per-stream kernel, 2 = uniform kernel
-hipError_t launch_demod(const DemodArgs& a, hipStream_t) { g_last = a; g_last_kind = 1; return hipSuccess; }
-hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t) { g_last = a; g_last_kind = 2; return hipSuccess; }
+static std::mutex g_last_mu;                                // (host entries are called from several threads at once)
+hipError_t launch_demod(const DemodArgs& a, hipStream_t) { std::lock_guard<std::mutex> lk(g_last_mu); g_last = a; g_last_kind = 1; return hipSuccess; }
+hipError_t launch_demod_uniform(const DemodArgs& a, hipStream_t) { std::lock_guard<std::mutex> lk(g_last_mu); g_last = a; g_last_kind = 2; return hipSuccess; }
 hipError_t launch_modulate(ModulateArgs, int32_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_noise(NoiseArgs, int32_t, hipStream_t) { return hipSuccess; }
 }
 extern "C" int afsk_stub_last_launch(int32_t* out_index, int32_t cap, int32_t* out_uniform_bf, int32_t* out_n) {
+    std::lock_guard<std::mutex> lk(afsk::g_last_mu);
     if (out_uniform_bf) *out_uniform_bf = afsk::g_last.uniform_bit_frames;
     if (out_n) *out_n = afsk::g_last.n_streams;
     if (!afsk::g_last.stream_index) return -afsk::g_last_kind;          // no index list: stream order

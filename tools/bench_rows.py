@@ -450,7 +450,8 @@ def measure_ragged(ctx: Ctx, reps: int = 10, seconds: int = 65536, baud: int = 1
                               plan=plan, entry="auto" if plan is not None else "uniform", stream=ctx.cur)
         b["out"].flat.zero_()
         with torch.cuda.stream(ctx.cur):
-            avg, med, _ = event_timed(torch, ctx.cur, launch, reps)
+            # (a fresh 6 GB allocation and cold clocks: ~50 ms of the same launches first, like bench.measure's pre-roll)
+            avg, med, _ = event_timed(torch, ctx.cur, launch, reps, warm=50)
         res = b["out"].cpu()
         pays = res.payloads()
         ok = sum(pays[s] == b["payload"][s, : b["plen"][s]].tobytes() for s in range(b["n"])) / b["n"]
