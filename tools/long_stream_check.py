@@ -1,5 +1,9 @@
 """GPU vs oracle on long streams (many ring laps, several deferred ECC flushes) at every rate a Receiver
-can be built for, through both device entries (diagnostic)."""
+can be built for, through both device entries (diagnostic).
+    python tools/long_stream_check.py [filler]
+filler (r6, default 0): that many short streams (4200 ... 9000 samples, random leads: every ring shift) are added to
+every launch, so that with filler >= 8192 the LARGE-launch kernels run -- L2 warming, tail hint, and the re-based ring
+with its ODD round forms -- on streams of 0.3 - 1.6 M samples."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +14,7 @@ from oracle import afsk_oracle as O
 afskmodem.LOG_LEVEL = 5
 rng = np.random.default_rng(5)
 bad = 0
+FILLER = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 2500, True), (3000, 2000, True), (2400, 1800, True),
                             (2000, 1500, True), (1500, 1200, True), (1000, 800, True), (750, 600, True), (600, 500, True), (300, 260, True),
                             (800, 650, True), (500, 420, True), (480, 400, True), (400, 340, True),
@@ -25,20 +30,28 @@ for baud, nbytes, quirk in ((12000, 6000, False), (6000, 3000, True), (4000, 250
         w = t.wav_samples(data) if quirk else np.concatenate([t.frames(data)])
         lead = rng.integers(-300, 300, int(rng.integers(0, 50))).astype(np.int16)
         pieces.append(np.concatenate([lead, w]))
+    if FILLER:
+        short = afskmodem.Transmitter(baud, 0.02).wav_samples(b"ok") if quirk else afskmodem.Transmitter(baud, 0.02).frames(b"ok")
+        for k in range(FILLER):
+            lead = rng.integers(-300, 300, int(rng.integers(0, 64))).astype(np.int16)
+            x = np.concatenate([lead, short])
+            pieces.append(np.concatenate([x, np.zeros(max(0, 4200 + (k % 7) * 8 - len(x)), np.int16)]))
+    n = len(pieces)
     ln = np.array([len(p) for p in pieces], np.int32)
     off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
     flat = np.concatenate(pieces)
     stride = int(nbytes + 64)
-    want = O.demod_batch(flat, off, ln, np.full(6, bf, np.int32), 14000, out_stride=stride, n_threads=6)
+    want = O.demod_batch(flat, off, ln, np.full(n, bf, np.int32), 14000, out_stride=stride, n_threads=16)
     b = 0
     for entry in ("uniform", "mixed"):
         res = batch.demod_batch(torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(),
-                                bf if entry == "uniform" else np.full(6, bf, np.int32), 14000, out_stride=stride, entry=entry).cpu()
+                                bf if entry == "uniform" else torch.full((n,), bf, dtype=torch.int32, device="cuda"), 14000,
+                                out_stride=stride, entry=entry).cpu()
         for f in ("nbytes", "nbits", "clock_idx", "term_frame", "status"):
             b += int((getattr(res, f) != want[f]).sum())
-        for i in range(6):
+        for i in range(n):
             nb = min(int(want["nbytes"][i]), stride)
             b += int((res.bytes[i, :nb] != want["bytes"][i, :nb]).any())
-    print(baud, "samples", int(ln.max()), "nbytes", want["nbytes"].tolist(), "mismatches", b, flush=True)
+    print(baud, "streams", n, "samples", int(ln.max()), "nbytes", want["nbytes"][:6].tolist(), "mismatches", b, flush=True)
     bad += b
 print("TOTAL", bad)
