@@ -75,7 +75,10 @@ int afsk_sync(void *hip_stream);
  * __bitsToBytes (:393-399) for n_streams independent streams at once.
  *
  *  samples        int16 mono 48 kHz, all streams in one allocation
- *  stream_offset  [n] first sample of stream s, in samples from `samples`
+ *  stream_offset  [n] first sample of stream s, in samples from `samples`.  Any value works (streams
+ *                 need 2-byte alignment only); EVEN offsets from a dword-aligned `samples` -- best:
+ *                 multiples of 8 samples -- run at full speed: a stream that starts on an odd sample
+ *                 is fetched by 2-byte-aligned requests, about 25 % slower (same results)
  *  stream_len     [n] length of stream s in samples (0 ... AFSK_MAX_STREAM_LEN; anything else:
  *                 status AFSK_ST_BAD_LENGTH for that stream, its neighbours are unaffected)
  *  bit_frames     [n] 48000 / baud of stream s (Receiver.__init__ :277);
