@@ -549,6 +549,8 @@ class GateResult:
     burst_len: "object"      # int32 [n, max_bursts], multiples of 2048
     open_end: "object"       # int32 [n]
     block_amp: "object"      # int32 [n, max_blocks]: int(sum|x| / 2048) per 2048-frame block
+    slot_offset: "object" = None   # int64 [n, max_bursts] (gate_batch(..., slots=True)): absolute first sample per slot
+    slot_len: "object" = None      # int32 [n, max_bursts]: burst length per slot, 0 = no such burst
 
     def burst_streams(self, stream_offset):
         """Flatten the bursts into (owner_stream int64 [m], offset int64 [m], length int32 [m])
@@ -566,6 +568,8 @@ class GateResult:
         [n * max_bursts], length int32 [n * max_bursts]), length 0 where capture s has fewer than k + 1 bursts (the
         demodulator answers such a slot with status TOO_SHORT and touches no sample).  gate -> burst_slots ->
         demod_batch is a chain of asynchronous launches and can be captured into one HIP graph."""
+        if self.slot_len is not None:          # r6: written by the gate kernel itself (afsk_gate_batch_slots)
+            return self.slot_offset.reshape(-1), self.slot_len.reshape(-1)
         torch = _torch()
         nb = self.burst_start.shape[1]
         mask = torch.arange(nb, device=self.n_bursts.device)[None, :] < self.n_bursts[:, None]
@@ -576,10 +580,13 @@ class GateResult:
 
 def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
                amp_start_threshold: int = 18000, amp_end_threshold: int = 14000,
-               max_bursts: int = 16, stream=None) -> GateResult:
+               max_bursts: int = 16, stream=None, slots: bool = True) -> GateResult:
     """Replay ``Receiver.__listen`` (ref:299-319) over n captures resident in HBM: 2048-frame
     block amplitudes, start above ``amp_start_threshold``, stop at the first block below
-    ``amp_end_threshold``; repeated receive() calls until each capture is exhausted."""
+    ``amp_end_threshold``; repeated receive() calls until each capture is exhausted.
+    ``slots`` (r6, ``afsk_gate_batch_slots``): the gate also lays the bursts out as fixed demodulator slots
+    (``GateResult.slot_offset / slot_len``, what ``burst_slots`` returns) -- gate -> demod then needs no arithmetic
+    in between."""
     torch = _torch()
     _native.require_device()
     if not (isinstance(samples, torch.Tensor) and samples.is_cuda and samples.dtype == torch.int16
@@ -595,12 +602,19 @@ def gate_batch(samples, stream_offset, stream_len, max_stream_len: int,
     with torch.cuda.device(dev):
         res = GateResult(i32(n), i32(n, max(max_bursts, 1)), i32(n, max(max_bursts, 1)), i32(n),
                          i32(n, max(max_blocks, 1)))
+        if slots and max_bursts > 0:
+            res.slot_offset = torch.zeros((n, int(max_bursts)), dtype=torch.int64, device=dev)
+            res.slot_len = i32(n, int(max_bursts))
         _order_after_current(stream, dev)          # the zero fills above ran on torch's current stream
-        _native.check(_native.lib().afsk_gate_batch(
-            samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
-            threshold_gt(amp_start_threshold), threshold_lt(amp_end_threshold), n, int(max_bursts),
-            res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
-            res.burst_len.data_ptr(), res.open_end.data_ptr(), _stream_ptr(stream, dev)))
+        args = (samples.data_ptr(), stream_offset.data_ptr(), stream_len.data_ptr(), int(max_stream_len),
+                threshold_gt(amp_start_threshold), threshold_lt(amp_end_threshold), n, int(max_bursts),
+                res.block_amp.data_ptr(), res.n_bursts.data_ptr(), res.burst_start.data_ptr(),
+                res.burst_len.data_ptr(), res.open_end.data_ptr())
+        if res.slot_len is not None:
+            _native.check(_native.lib().afsk_gate_batch_slots(*args, res.slot_offset.data_ptr(), res.slot_len.data_ptr(),
+                                                              _stream_ptr(stream, dev)))
+        else:
+            _native.check(_native.lib().afsk_gate_batch(*args, _stream_ptr(stream, dev)))
     return res
 
 

@@ -1869,12 +1869,12 @@ int afsk_modulate_batch(const uint8_t* payload, int32_t payload_stride,
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch modulate_kernel");
 }
 
-int afsk_gate_batch(const int16_t* samples, const int64_t* stream_offset,
-                    const int32_t* stream_len, int32_t max_stream_len,
-                    int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
-                    int32_t max_bursts, int32_t* block_amp, int32_t* out_n_bursts,
-                    int32_t* out_burst_start, int32_t* out_burst_len, int32_t* out_open_end,
-                    void* hip_stream) {
+static int gate_batch_impl(const int16_t* samples, const int64_t* stream_offset,
+                           const int32_t* stream_len, int32_t max_stream_len,
+                           int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
+                           int32_t max_bursts, int32_t* block_amp, int32_t* out_n_bursts,
+                           int32_t* out_burst_start, int32_t* out_burst_len, int32_t* out_open_end,
+                           int64_t* out_slot_offset, int32_t* out_slot_len, void* hip_stream) {
     if (n_streams < 0 || max_stream_len < 0 || max_bursts < 0)
         return fail(AFSK_E_INVALID_ARG, "negative size");
     if (n_streams == 0) return AFSK_OK;
@@ -1882,6 +1882,8 @@ int afsk_gate_batch(const int16_t* samples, const int64_t* stream_offset,
     if (!samples || !stream_offset || !stream_len || !out_n_bursts || !out_open_end ||
         (max_blocks > 0 && !block_amp) || (max_bursts > 0 && (!out_burst_start || !out_burst_len)))
         return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    if ((out_slot_offset == nullptr) != (out_slot_len == nullptr))
+        return fail(AFSK_E_INVALID_ARG, "out_slot_offset and out_slot_len go together");
     if (int rc = require_device()) return rc;
     afsk::GateArgs a;
     a.samples = samples; a.stream_offset = stream_offset; a.stream_len = stream_len;
@@ -1890,8 +1892,33 @@ int afsk_gate_batch(const int16_t* samples, const int64_t* stream_offset,
     a.max_blocks = max_blocks; a.max_bursts = max_bursts; a.block_amp = block_amp;
     a.out_n_bursts = out_n_bursts; a.out_burst_start = out_burst_start;
     a.out_burst_len = out_burst_len; a.out_open_end = out_open_end;
+    a.out_slot_offset = max_bursts > 0 ? out_slot_offset : nullptr;
+    a.out_slot_len = max_bursts > 0 ? out_slot_len : nullptr;
     hipError_t e = afsk::launch_gate(a, (hipStream_t)hip_stream);
     return e == hipSuccess ? AFSK_OK : hip_fail(e, "launch gate kernels");
+}
+
+int afsk_gate_batch(const int16_t* samples, const int64_t* stream_offset,
+                    const int32_t* stream_len, int32_t max_stream_len,
+                    int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
+                    int32_t max_bursts, int32_t* block_amp, int32_t* out_n_bursts,
+                    int32_t* out_burst_start, int32_t* out_burst_len, int32_t* out_open_end,
+                    void* hip_stream) {
+    return gate_batch_impl(samples, stream_offset, stream_len, max_stream_len, amp_start_threshold, amp_end_threshold,
+                           n_streams, max_bursts, block_amp, out_n_bursts, out_burst_start, out_burst_len, out_open_end,
+                           nullptr, nullptr, hip_stream);
+}
+
+int afsk_gate_batch_slots(const int16_t* samples, const int64_t* stream_offset,
+                          const int32_t* stream_len, int32_t max_stream_len,
+                          int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
+                          int32_t max_bursts, int32_t* block_amp, int32_t* out_n_bursts,
+                          int32_t* out_burst_start, int32_t* out_burst_len, int32_t* out_open_end,
+                          int64_t* out_slot_offset, int32_t* out_slot_len, void* hip_stream) {
+    if (max_bursts > 0 && (!out_slot_offset || !out_slot_len)) return fail(AFSK_E_INVALID_ARG, "null pointer argument");
+    return gate_batch_impl(samples, stream_offset, stream_len, max_stream_len, amp_start_threshold, amp_end_threshold,
+                           n_streams, max_bursts, block_amp, out_n_bursts, out_burst_start, out_burst_len, out_open_end,
+                           out_slot_offset, out_slot_len, hip_stream);
 }
 
 int afsk_add_noise_batch(int16_t* samples, const int64_t* stream_offset,

@@ -8,7 +8,8 @@
 //   gate_scan_kernel  one thread per capture walks its block amplitudes through the
 //                     listen state machine: discard one block (ref:303), wait for
 //                     amp > amp_start (ref:306), record through the first amp < amp_end
-//                     (ref:316), repeat for the next receive() call.
+//                     (ref:316), repeat for the next receive() call; optionally (r6) it also lays the
+//                     bursts out as fixed demodulator slots (absolute offset + length per slot).
 #include "afsk_kernels.h"
 
 namespace afsk {
@@ -63,6 +64,11 @@ __global__ __launch_bounds__(256) void gate_scan_kernel(GateArgs a) {
     if ((uint32_t)len > (uint32_t)a.max_len) {               // refused capture: out_n_bursts = -1, no burst written
         a.out_n_bursts[s] = -1;
         a.out_open_end[s] = 0;
+        if (a.out_slot_len)
+            for (int k = 0; k < a.max_bursts; k++) {
+                a.out_slot_offset[(int64_t)s * a.max_bursts + k] = 0;
+                a.out_slot_len[(int64_t)s * a.max_bursts + k] = 0;
+            }
         return;
     }
     const int32_t nb = len / kListenBlock;
@@ -92,6 +98,16 @@ __global__ __launch_bounds__(256) void gate_scan_kernel(GateArgs a) {
     }
     a.out_n_bursts[s] = n;
     a.out_open_end[s] = open_end;
+    // the bursts as demodulator slots (afsk_gate_batch_slots): what Receiver.receive hands to __decodeBits (ref:402-417),
+    // ready for afsk_demod_batch* without a host round trip or any arithmetic in between; unused slots get length 0
+    // (the demodulator answers them with AFSK_ST_TOO_SHORT and reads nothing)
+    if (a.out_slot_len) {
+        const int64_t base = a.stream_offset[s];
+        for (int k = 0; k < a.max_bursts; k++) {
+            a.out_slot_offset[(int64_t)s * a.max_bursts + k] = k < n ? base + bs[k] : 0;
+            a.out_slot_len[(int64_t)s * a.max_bursts + k] = k < n ? bl[k] : 0;
+        }
+    }
 }
 
 hipError_t launch_gate(const GateArgs& a, hipStream_t stream) {

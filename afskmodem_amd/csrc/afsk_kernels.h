@@ -95,6 +95,10 @@ struct GateArgs {
     int32_t* out_burst_start;
     int32_t* out_burst_len;
     int32_t* out_open_end;
+    // optional (afsk_gate_batch_slots): the bursts as fixed demodulator slots -- slot s * max_bursts + k = burst k of
+    // capture s as (absolute first sample, length); length 0 (and offset 0) where capture s has fewer bursts
+    int64_t* out_slot_offset = nullptr;   // [n_streams, max_bursts]
+    int32_t* out_slot_len = nullptr;      // [n_streams, max_bursts]
 };
 
 hipError_t launch_gate(const GateArgs& a, hipStream_t stream);

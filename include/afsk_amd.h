@@ -349,6 +349,15 @@ int afsk_modulate_batch(const uint8_t *payload, int32_t payload_stride,
  *                   block (a live receiver would still be recording)
  * The bursts are demodulated by passing stream_offset[s] + out_burst_start[s,k] and
  * out_burst_len[s,k] to afsk_demod_batch.
+ *
+ * afsk_gate_batch_slots (r6, an addition) does that arithmetic on the device as well: it also writes the bursts as
+ * FIXED demodulator slots -- slot s * max_bursts + k = burst k of capture s:
+ *  out_slot_offset  int64 [n, max_bursts] stream_offset[s] + out_burst_start[s,k]; 0 where capture s has fewer bursts
+ *  out_slot_len     int32 [n, max_bursts] out_burst_len[s,k]; 0 where capture s has fewer bursts (afsk_demod_batch*
+ *                   answers such a slot with AFSK_ST_TOO_SHORT and reads nothing)
+ * so that  afsk_gate_batch_slots(...) ; afsk_demod_batch_uniform(samples, out_slot_offset, out_slot_len, bit_frames,
+ * amp_end, n * max_bursts, ...)  on one stream is what repeated Receiver.receive() calls do (:402-417) for n captures,
+ * with no host round trip in between (two launches + one: capturable into one HIP graph).
  */
 int afsk_gate_batch(const int16_t *samples, const int64_t *stream_offset,
                     const int32_t *stream_len, int32_t max_stream_len,
@@ -356,6 +365,12 @@ int afsk_gate_batch(const int16_t *samples, const int64_t *stream_offset,
                     int32_t max_bursts, int32_t *block_amp, int32_t *out_n_bursts,
                     int32_t *out_burst_start, int32_t *out_burst_len, int32_t *out_open_end,
                     void *hip_stream);
+int afsk_gate_batch_slots(const int16_t *samples, const int64_t *stream_offset,
+                          const int32_t *stream_len, int32_t max_stream_len,
+                          int32_t amp_start_threshold, int32_t amp_end_threshold, int32_t n_streams,
+                          int32_t max_bursts, int32_t *block_amp, int32_t *out_n_bursts,
+                          int32_t *out_burst_start, int32_t *out_burst_len, int32_t *out_open_end,
+                          int64_t *out_slot_offset, int32_t *out_slot_len, void *hip_stream);
 
 /*
  * Deterministic additive noise (build-owned test/benchmark input generator, no

@@ -110,6 +110,14 @@ def test_listen_gate_vs_reference_and_oracle(golden, torch_cuda):
         torch.cuda.synchronize()
         nb, bs, bl, oe, amp = (t.cpu().numpy() for t in (g.n_bursts, g.burst_start, g.burst_len,
                                                           g.open_end, g.block_amp))
+        # (r6) afsk_gate_batch_slots: the bursts once more, as absolute demodulator slots written by the gate kernel --
+        # equal to the arithmetic burst_slots used to do with torch operations on the plain entry's outputs
+        plain = batch.gate_batch(samples, off, ln, max_len, a_start, a_end, 16, slots=False)
+        assert plain.slot_len is None and g.slot_len is not None
+        for a_, b_ in zip(plain.burst_slots(off), g.burst_slots(off)):
+            assert torch.equal(a_, b_)
+        for f in ("n_bursts", "burst_start", "burst_len", "open_end", "block_amp"):
+            assert torch.equal(getattr(plain, f), getattr(g, f)), f
         for i, c in enumerate(cases):
             want = [(b["start"], b["len"]) for b in c["bursts"]]
             got = [(int(bs[i, k]), int(bl[i, k])) for k in range(nb[i])]

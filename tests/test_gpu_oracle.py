@@ -445,6 +445,13 @@ def test_device_side_lengths_are_guarded_in_the_kernels(torch_cuda):
         assert int(nb[i]) == len(bursts) and int(g.open_end[i].item()) == oe
     owner, _, _ = g.burst_streams(t(g_off))
     assert not set(owner.cpu().numpy().tolist()) & {3, 17, 40}
+    # (r6) the gate's own demodulator slots: a refused capture gets empty slots, every other one its bursts
+    so, sl = g.slot_offset.cpu().numpy(), g.slot_len.cpu().numpy()
+    assert not sl[[3, 17, 40]].any() and not so[[3, 17, 40]].any()
+    for i in (0, 2, 4, 16, 18, 63):
+        bursts, _ = O.gate_stream(x[i * L: (i + 1) * L], 18000, 14000, 4)
+        assert [(int(so[i, k]) - i * L, int(sl[i, k])) for k in range(len(bursts))] == bursts
+        assert not sl[i, len(bursts):].any()
 
     # modulator + noise: a poisoned stream keeps whatever the buffer held
     ns = 8
