@@ -367,9 +367,10 @@ class GroupPlan:
         # Not inside a HIP stream capture (the last DemodResult of a cached plan may be dropped there, e.g. by
         # rebinding ``res = demod_batch(...)`` while capturing): a synchronise would invalidate the capture, so the
         # handle is parked and freed by the next plan construction / explicit ``release_parked_plans()`` outside one.
-        h, self._h = self._h, C.c_void_p()
+        h = getattr(self, "_h", None)          # (a constructor that raised before the plan existed)
         if not h:
             return
+        self._h = C.c_void_p()
         try:
             torch = _torch()
             if torch.cuda.is_current_stream_capturing():

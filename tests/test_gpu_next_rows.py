@@ -226,6 +226,39 @@ def test_native_wav_ingest_raw_riff_cases(golden, torch_cuda, tmp_path):
     assert got == [bytes([65 + (i % 8)]) * (20 + (i % 8)) for i in range(700)]
 
 
+def test_plan_freed_inside_a_stream_capture_is_parked_not_synchronised(torch_cuda, entry):
+    """r5 advisor: the last reference to a cached plan may go away INSIDE a HIP stream capture (rebinding the result of
+    a demod_batch call while capturing).  GroupPlan.__del__ must not synchronise the device there -- that would
+    invalidate the capture -- but park the handle; the next plan construction (or release_parked_plans) frees it."""
+    if entry != "grouped":
+        pytest.skip("entry-independent: runs once")
+    torch = torch_cuda
+    b = synth_batch(torch, 64, (1200, 300, 2400, 600, 800), seed=77)
+    stride = batch.out_stride_for(48000, int(b["h_bf"].min()))
+    res = REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], b["h_bf"], 14000, out_stride=stride, entry="grouped")
+    torch.cuda.synchronize()
+    want = res.cpu()
+    with batch._PLAN_CACHE_LOCK:
+        batch._PLAN_CACHE.clear()                 # the result now holds the only reference to its plan
+    out = batch.alloc_result(64, stride, "cuda:0")
+    plan = batch.GroupPlan(b["h_bf"], "cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    before = len(batch._PARKED_PLANS)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            REAL_DEMOD_BATCH(b["samples"], b["off"], b["ln"], None, 14000, out=out, plan=plan)
+            del res                               # -> GroupPlan.__del__ while capturing
+    assert len(batch._PARKED_PLANS) == before + 1
+    graph.replay()                                # the capture survived
+    torch.cuda.synchronize()
+    got = out.cpu()
+    for f in FIELDS:
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    assert batch.release_parked_plans() == 0
+
+
 def test_grouped_dispatch_plan_api(torch_cuda, entry):
     """afsk_group_plan_* / afsk_demod_batch_grouped directly (not through the `entry` fixture): bucket order and
     counts, a plan reused across launches and thresholds, status 3 for streams whose host-side bit_frames is

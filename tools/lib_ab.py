@@ -38,6 +38,7 @@ def main() -> None:
                     help="K > 1: stream s reads the samples of stream (s %% K) * (n / K) + s / K -- a stream-order walk then jumps "
                          "through the input like a rate-sorted walk over K cycling rates (the round-trip figure is meaningless then)")
     ap.add_argument("--stride-align", type=int, default=0, help="round the output row stride up to a multiple of this (0: bench.py's)")
+    ap.add_argument("--lead", default="", help="lead-in before every frame: N samples or 'random' (bench.py --lead)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -45,6 +46,10 @@ def main() -> None:
     bauds = tuple(int(b) for b in a.bauds.split(","))
     bench.WORKLOADS["custom"] = (a.streams, bauds, None, f"custom {bauds}")
     bench.RATE_ORDER = a.rate_order
+    if a.lead == "random":
+        bench.LEADS["custom"] = 2048
+    elif a.lead:
+        bench.LEAD_FIXED["custom"] = int(a.lead)
     args = types.SimpleNamespace(gpus=1, share_gpu0=False, force_gather=False, dist_backend="nccl", entry=a.entry,
                                  pg_timeout_s=90.0)
     os.environ.setdefault("AFSK_BENCH_VERBOSE", "0")
@@ -70,8 +75,9 @@ def main() -> None:
             os.environ.pop("AFSK_GROUP_SORT_FROM", None)
         L = C.CDLL(os.path.abspath(path))
         for name, (res, at) in _native.SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype, fn.argtypes = res, at
+            fn = getattr(L, name, None)                   # (an older build lacks the entries added since)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, at
         o = batch.alloc_result(n, stride, ctx.dev)
         if sh.uniform_bf is not None:
             fn = L.afsk_demod_batch_uniform
