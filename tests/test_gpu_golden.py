@@ -168,6 +168,46 @@ def test_golden_cases_device_entry(golden, torch_cuda):
         assert got == (c["clock_idx"], c["term_frame"], c["nbits"], c["bytes_hex"]), c["tag"]
 
 
+def test_golden_cases_inside_large_launches(golden, torch_cuda, entry):
+    """r6: the reference's own vectors through the LARGE-launch kernels -- tail hint, L2 warming, the ring re-based on
+    the clock index and the ODD round forms are armed from 4096 / 6144 / 8192 (bit_frames 8: 16384) streams on, and a
+    batch of a few hundred golden cases alone never gets there.  The golden cases are repeated until a launch holds 8400
+    streams: all rates in one launch (per-stream and grouped entry), and -- uniform entry -- the cases of 1200 / 2400 /
+    300 / 12000 / 6000 baud each in a launch of their own (6000 baud: 16500 streams).  EVERY copy must give the values
+    recorded from inside the reference."""
+    all_cases = [c for c in golden["decode_cases"] if c["amp_end"] == 14000]
+    inputs = {c["tag"]: build_input(c) for c in all_cases}
+
+    def run(cases, n, seed):
+        order = np.tile(np.arange(len(cases)), -(-n // len(cases)))[:n]
+        np.random.default_rng(seed).shuffle(order)             # neighbours in a workgroup differ in rate and length
+        xs = [inputs[cases[i]["tag"]] for i in order]
+        ln = np.array([len(x) for x in xs], np.int32)
+        pad = (-ln) % 8                                        # streams start on 16 bytes (what upload_streams gives)
+        off = np.concatenate([[0], np.cumsum((ln + pad)[:-1], dtype=np.int64)]).astype(np.int64)
+        flat = np.zeros(int(off[-1] + ln[-1]), np.int16)
+        for j, x in enumerate(xs):
+            flat[off[j]: off[j] + ln[j]] = x
+        bf = np.array([48000 // cases[i]["baud"] for i in order], np.int32)
+        res = device_demod(torch_cuda, flat, off, ln, bf, stride=max(64, max(len(c["bytes_hex"]) // 2 for c in cases) + 8))
+        pl = res.payloads()
+        bad = []
+        for j, i in enumerate(order):
+            c = cases[i]
+            got = (int(res.clock_idx[j]), int(res.term_frame[j]), int(res.nbits[j]), pl[j].hex())
+            if got != (c["clock_idx"], c["term_frame"], c["nbits"], c["bytes_hex"]):
+                bad.append((c["tag"], j, got[:3]))
+        assert not bad, (len(bad), bad[:5])
+        return res
+
+    if entry != "uniform":
+        res = run(all_cases, 8400, 9)
+        assert len({(2 * int(c)) & 15 for c in res.clock_idx if c >= 0}) == 8      # every ring shift occurred
+    else:
+        for baud, n in ((1200, 8400), (2400, 8400), (300, 8400), (12000, 8400), (6000, 16500)):
+            run([c for c in all_cases if c["baud"] == baud], n, baud)
+
+
 def test_soft_outputs_golden_cases(golden, torch_cuda):
     """afsk_demod_batch_ex: corrected-codeword counts and per-symbol margins against the values
     recorded from inside the reference (make_golden.py, ``soft``), every decode case, one
