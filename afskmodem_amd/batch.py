@@ -370,7 +370,7 @@ class GroupPlan:
         h = getattr(self, "_h", None)          # (a constructor that raised before the plan existed)
         if not h:
             return
-        self._h = C.c_void_p()
+        self._h = None                         # (not C.c_void_p(): module globals may be gone at interpreter shutdown)
         try:
             torch = _torch()
             if torch.cuda.is_current_stream_capturing():

@@ -62,8 +62,12 @@ for baud in (1200, 2400, 600, 300, 12000, 6000, 4000, 3000, 2000, 1500, 1000, 75
         x = torch.from_numpy(flat).cuda()
         d_off, d_ln = torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda()
         late = int((want["clock_idx"] >= 4096 - 2 * bf - 72).sum())
-        for entry in entries:
-            res = batch.demod_batch(x, d_off, d_ln, bf if entry == "uniform" else bfa, amp_end, out_stride=64, entry=entry)
+        # (r6) "planned": one rate through a length-aware plan -- the uniform kernel walking the longest-first index list
+        for entry in entries + (["planned"] if "uniform" in entries and batch.lengths_ragged(ln) else []):
+            if entry == "planned":
+                res = batch.demod_batch(x, d_off, d_ln, bf, amp_end, out_stride=64, stream_len_host=ln)
+            else:
+                res = batch.demod_batch(x, d_off, d_ln, bf if entry == "uniform" else bfa, amp_end, out_stride=64, entry=entry)
             torch.cuda.synchronize()
             got = res.cpu()
             bad = 0
@@ -108,8 +112,10 @@ x = torch.from_numpy(flat).cuda()
 d_off, d_ln, d_bf = torch.from_numpy(off).cuda(), torch.from_numpy(ln).cuda(), torch.from_numpy(bfa).cuda()
 for amp_end in (14000, 0, 22000):
     want = O.demod_batch(flat, off, ln, bfa, amp_end, out_stride=64, n_threads=os.cpu_count() or 8)
-    for entry, arg in (("mixed", d_bf), ("grouped", bfa)):
-        got = batch.demod_batch(x, d_off, d_ln, arg, amp_end, out_stride=64, entry=entry).cpu()
+    for entry, arg in (("mixed", d_bf), ("grouped", bfa), ("planned", bfa)):
+        # (r6) "planned": the grouped dispatch with the host-side lengths -- rate buckets, each longest first
+        got = batch.demod_batch(x, d_off, d_ln, arg, amp_end, out_stride=64, entry="grouped" if entry == "planned" else entry,
+                                stream_len_host=ln if entry == "planned" else None).cpu()
         bad = sum(int((getattr(got, f) != want[f]).sum()) for f in FIELDS)
         nb = np.minimum(want["nbytes"], 64)
         bad += int(((got.bytes != want["bytes"]) & (np.arange(64)[None, :] < nb[:, None])).any(axis=1).sum())
