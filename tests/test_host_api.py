@@ -574,3 +574,20 @@ def test_plan_cache_is_thread_safe_and_never_closes_a_plan_in_use(monkeypatch):
     p1 = batch._cached_plan(arr, 16, "cuda:0", ragged)
     assert p1 is not p0 and np.array_equal(p1.stream_len, ragged) and batch._cached_plan(arr, 16, "cuda:0", ragged) is p1
     assert batch._cached_plan(arr, 16, "cuda:0", ragged[::-1].copy()) is not p1
+
+
+def test_shell_scripts_parse_and_find_the_repository_root():
+    """tools/*.sh, tools/experiments/*.sh (moved there in r6), build.sh and the test helpers: valid bash, and every
+    experiment script changes into the repository root (or tools/) relative to ITS OWN location."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = (glob.glob(os.path.join(root, "tools", "*.sh")) + glob.glob(os.path.join(root, "tools", "experiments", "*.sh"))
+               + glob.glob(os.path.join(root, "tests", "helpers", "*.sh")) + [os.path.join(root, "afskmodem_amd", "csrc", "build.sh")])
+    assert len(scripts) > 60
+    for f in scripts:
+        r = subprocess.run(["bash", "-n", f], capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stderr)
+    for f in glob.glob(os.path.join(root, "tools", "experiments", "*.sh")):
+        text = open(f).read()
+        assert 'cd "$(dirname "$0")/../.."' in text or 'cd "$(dirname "$0")/.."' in text, f

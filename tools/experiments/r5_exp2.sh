@@ -1,7 +1,7 @@
 #!/bin/bash
 # r5 kernel variants against the r4 library, both loaded into ONE kbench process (interleaved launches, outputs
-# compared with the independent two-pass baseline): bash tools/r5_exp2.sh "<libs, colon separated>" "<bauds>" [streams]
-cd "$(dirname "$0")"
+# compared with the independent two-pass baseline): bash tools/experiments/r5_exp2.sh "<libs, colon separated>" "<bauds>" [streams]
+cd "$(dirname "$0")/.."   # (tools/: kbench lives there)
 export KBENCH_LIB_B=$1 KBENCH_NO_MIXED=1
 for n in ${3:-65536}; do
 for b in $2; do
