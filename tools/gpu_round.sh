@@ -14,6 +14,13 @@ T=$PROF_TAG
 if [ -z "${SKIP_TESTS:-}" ]; then
 ( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) | tee gpurun_out/${T}_pytest_gpu.log
 fi
+# The validated escape hatch stays validated: when tools/libafsk_safe.so exists (AFSK_SAFE_CODEGEN=1 AFSK_OUT=$PWD/tools/libafsk_safe.so
+# bash afskmodem_amd/csrc/build.sh -- the build WITHOUT the LLVM-internal code-generation flag) the kernel-facing test
+# files run against it too, and both builds decode one resident batch in one process with their outputs compared
+if [ -z "${SKIP_TESTS:-}" ] && [ -f tools/libafsk_safe.so ] && [ tools/libafsk_safe.so -nt afskmodem_amd/csrc/afsk_demod_ring.h ]; then
+  ( AFSK_AMD_LIB=$PWD/tools/libafsk_safe.so timeout 900 python -m pytest tests/test_gpu_golden.py tests/test_gpu_oracle.py tests/test_gpu_rounds.py tests/test_gpu_lead.py -q -m gpu 2>&1 | tail -3 ) | tee gpurun_out/${T}_pytest_gpu_safe_codegen.log
+  ( timeout 300 python tools/lib_ab.py --bauds 300,1200,2400,4000 --lead random afskmodem_amd/csrc/libafsk_amd.so tools/libafsk_safe.so 2>&1 | tail -3 ) | tee -a gpurun_out/${T}_pytest_gpu_safe_codegen.log
+fi
 if [ -z "${PROF_ONLY:-}" ]; then
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) | tee gpurun_out/${T}_smoke.log
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/${T}_bench_main.err | grep '^{"metric"' ) > gpurun_out/${T}_bench_main.json
